@@ -1,0 +1,194 @@
+"""Thin object layer over the C ABI: one ``Context`` per GPU, ``DeviceServerKey`` per key.
+
+Host entry points take numpy arrays; device entry points take torch CUDA tensors (torch is
+only the owner of device memory and streams here). Everything computes in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import CAMD_PBS_AUTO, CAMD_PBS_GENERIC, CAMD_PBS_WAVE, check  # noqa: F401
+
+
+def _np_ptr(a: np.ndarray):
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous")
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One per (process, GPU). Replaces the reference's thread-local engines."""
+
+    def __init__(self, device_id: int = 0):
+        self._h = C.c_void_p()
+        check(_ffi.lib().camd_context_create(int(device_id), C.byref(self._h)))
+        self.device_id = int(device_id)
+
+    def synchronize(self) -> None:
+        check(_ffi.lib().camd_context_synchronize(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            _ffi.lib().camd_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceServerKey:
+    """Fourier bootstrap key + keyswitch key + look-up tables resident on one GPU."""
+
+    def __init__(self, ctx: Context, handle: C.c_void_p, params, torus_bits: int):
+        self.ctx = ctx
+        self._h = handle
+        self.params = params
+        self.torus_bits = torus_bits
+        self.dtype = np.uint64 if torus_bits == 64 else np.uint32
+        self.n = int(params.lwe_dimension)
+        self.big = int(params.glwe_dimension) * int(params.polynomial_size)
+        self.glwe_words = (int(params.glwe_dimension) + 1) * int(params.polynomial_size)
+
+    # ---- construction ----
+    @classmethod
+    def from_standard_keys(cls, ctx: Context, params, bsk_standard: np.ndarray, ksk: np.ndarray,
+                           variant: int = CAMD_PBS_AUTO, torus_bits: int | None = None) -> "DeviceServerKey":
+        bits = torus_bits if torus_bits is not None else int(getattr(params, "torus_bits", 64))
+        dtype = np.uint64 if bits == 64 else np.uint32
+        n, k, N = int(params.lwe_dimension), int(params.glwe_dimension), int(params.polynomial_size)
+        bsk = np.ascontiguousarray(bsk_standard, dtype=dtype)
+        ks = np.ascontiguousarray(ksk, dtype=dtype)
+        if bsk.size != n * int(params.pbs_level) * (k + 1) * (k + 1) * N:
+            raise ValueError("bootstrap key has the wrong number of words for the parameter set")
+        if ks.size != k * N * int(params.ks_level) * (n + 1):
+            raise ValueError("keyswitch key has the wrong number of words for the parameter set")
+        cp = _ffi.make_params(params, bits)
+        h = C.c_void_p()
+        check(_ffi.lib().camd_server_key_create(ctx._h, C.byref(cp), _np_ptr(bsk), _np_ptr(ks), int(variant), C.byref(h)))
+        return cls(ctx, h, params, bits)
+
+    @classmethod
+    def from_device_blob(cls, ctx: Context, params, blob, variant: int, torus_bits: int | None = None,
+                         stream: int = 0) -> "DeviceServerKey":
+        """Adopt a copy of a key blob that is already on this GPU (a torch uint8 CUDA tensor)."""
+        bits = torus_bits if torus_bits is not None else int(getattr(params, "torus_bits", 64))
+        cp = _ffi.make_params(params, bits)
+        h = C.c_void_p()
+        check(_ffi.lib().camd_server_key_import_blob(ctx._h, C.byref(cp), int(variant), C.c_void_p(blob.data_ptr()),
+                                                     blob.numel() * blob.element_size(), C.c_void_p(stream), C.byref(h)))
+        return cls(ctx, h, params, bits)
+
+    @property
+    def variant(self) -> int:
+        v = C.c_int()
+        check(_ffi.lib().camd_server_key_variant(self._h, C.byref(v)))
+        return v.value
+
+    def blob_size(self) -> int:
+        s = C.c_size_t()
+        check(_ffi.lib().camd_server_key_blob_size(self._h, C.byref(s)))
+        return s.value
+
+    def export_blob(self, dst, stream: int = 0) -> None:
+        """Copy the device-resident key material into ``dst`` (torch uint8 CUDA tensor)."""
+        if dst.numel() * dst.element_size() < self.blob_size():
+            raise ValueError("destination tensor is smaller than the key blob")
+        check(_ffi.lib().camd_server_key_export_blob(self._h, C.c_void_p(dst.data_ptr()), C.c_void_p(stream)))
+
+    def close(self) -> None:
+        if self._h:
+            _ffi.lib().camd_server_key_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- look-up tables ----
+    def upload_lut(self, glwe: np.ndarray) -> int:
+        g = np.ascontiguousarray(glwe, dtype=self.dtype)
+        if g.size != self.glwe_words:
+            raise ValueError("look-up table must hold (k+1)*N words")
+        lut_id = C.c_uint32()
+        check(_ffi.lib().camd_lut_upload(self._h, _np_ptr(g), C.byref(lut_id)))
+        return lut_id.value
+
+    @property
+    def lut_count(self) -> int:
+        c = C.c_uint32()
+        check(_ffi.lib().camd_lut_count(self._h, C.byref(c)))
+        return c.value
+
+    # ---- host batches ----
+    def _host(self, fn, ct_in, lut_ids, in_words, out_words, with_ids=True):
+        a = np.ascontiguousarray(ct_in, dtype=self.dtype)
+        if a.ndim == 1:
+            a = a[None, :]
+        if a.ndim != 2 or a.shape[1] != in_words:
+            raise ValueError(f"expected ciphertexts of {in_words} words, got shape {a.shape}")
+        count = a.shape[0]
+        out = np.empty((count, out_words), dtype=self.dtype)
+        if with_ids:
+            ids = None
+            if lut_ids is not None:
+                ids = np.ascontiguousarray(lut_ids, dtype=np.uint32)
+                if ids.shape != (count,):
+                    raise ValueError("lut_ids must have one entry per ciphertext")
+            check(fn(self._h, _np_ptr(a), _np_ptr(ids) if ids is not None else None, _np_ptr(out), count))
+        else:
+            check(fn(self._h, _np_ptr(a), _np_ptr(out), count))
+        return out
+
+    def ks_pbs(self, ct_in, lut_ids=None) -> np.ndarray:
+        return self._host(_ffi.lib().camd_ks_pbs_batch, ct_in, lut_ids, self.big + 1, self.big + 1)
+
+    def pbs_ks(self, ct_in, lut_ids=None) -> np.ndarray:
+        return self._host(_ffi.lib().camd_pbs_ks_batch, ct_in, lut_ids, self.n + 1, self.n + 1)
+
+    def pbs(self, ct_in, lut_ids=None) -> np.ndarray:
+        return self._host(_ffi.lib().camd_pbs_batch, ct_in, lut_ids, self.n + 1, self.big + 1)
+
+    def ks(self, ct_in) -> np.ndarray:
+        return self._host(_ffi.lib().camd_ks_batch, ct_in, None, self.big + 1, self.n + 1, with_ids=False)
+
+    # ---- device batches (torch tensors own the memory) ----
+    def reserve(self, count: int) -> None:
+        check(_ffi.lib().camd_reserve(self._h, int(count)))
+
+    def _dev(self, fn, ct_in, lut_ids, ct_out, count, stream, with_ids=True):
+        ids_ptr = C.c_void_p(lut_ids.data_ptr()) if lut_ids is not None else None
+        if with_ids:
+            check(fn(self._h, C.c_void_p(ct_in.data_ptr()), ids_ptr, C.c_void_p(ct_out.data_ptr()), int(count),
+                     C.c_void_p(stream)))
+        else:
+            check(fn(self._h, C.c_void_p(ct_in.data_ptr()), C.c_void_p(ct_out.data_ptr()), int(count), C.c_void_p(stream)))
+
+    def ks_pbs_device(self, ct_in, lut_ids, ct_out, count: int, stream: int = 0) -> None:
+        self._dev(_ffi.lib().camd_ks_pbs_batch_device, ct_in, lut_ids, ct_out, count, stream)
+
+    def pbs_ks_device(self, ct_in, lut_ids, ct_out, count: int, stream: int = 0) -> None:
+        self._dev(_ffi.lib().camd_pbs_ks_batch_device, ct_in, lut_ids, ct_out, count, stream)
+
+    def pbs_device(self, ct_in, lut_ids, ct_out, count: int, stream: int = 0) -> None:
+        self._dev(_ffi.lib().camd_pbs_batch_device, ct_in, lut_ids, ct_out, count, stream)
+
+    def ks_device(self, ct_in, ct_out, count: int, stream: int = 0) -> None:
+        self._dev(_ffi.lib().camd_ks_batch_device, ct_in, None, ct_out, count, stream, with_ids=False)
+
+    # ---- measurement ----
+    def timing_enable(self, on: bool = True) -> None:
+        check(_ffi.lib().camd_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        pm, km = C.c_double(), C.c_double()
+        pn, kn = C.c_uint64(), C.c_uint64()
+        check(_ffi.lib().camd_timing_read(self._h, C.byref(pm), C.byref(pn), C.byref(km), C.byref(kn)))
+        return {"pbs_ms": pm.value, "pbs_launches": pn.value, "ks_ms": km.value, "ks_launches": kn.value}

@@ -1,0 +1,569 @@
+// C ABI of the backend: contexts, server keys, look-up tables, batch entry points.
+// The header (include/concrete_amd.h) documents which reference interface each entry replaces.
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace camd {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+}  // namespace camd
+
+using namespace camd;
+
+struct camd_context {
+  int device = 0;
+  hipStream_t stream = nullptr;  // used by the host-pointer entry points
+};
+
+namespace {
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return CAMD_OK;
+    if (ptr) {
+      CAMD_HIP(hipDeviceSynchronize());
+      CAMD_HIP(hipFree(ptr));
+      ptr = nullptr;
+      bytes = 0;
+    }
+    CAMD_HIP(hipMalloc(&ptr, need));
+    bytes = need;
+    return CAMD_OK;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+struct Timing {
+  bool enabled = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pbs, ks;
+  void clear() {
+    for (auto& e : pbs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : ks) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    pbs.clear();
+    ks.clear();
+  }
+};
+
+}  // namespace
+
+struct camd_server_key {
+  camd_context* ctx = nullptr;
+  camd_params p{};
+  int variant = CAMD_PBS_GENERIC;
+  size_t word = 8;          // bytes per torus word
+  // one blob: [fourier bsk | ksk]
+  void* blob = nullptr;
+  size_t fbsk_bytes = 0, ksk_bytes = 0;
+  double2* tables = nullptr;
+  // look-up tables
+  DeviceBuffer luts;
+  uint32_t lut_count = 0;
+  // scratch
+  DeviceBuffer mid;         // keyswitch output (shortint order) or bootstrap output (boolean order)
+  DeviceBuffer pbs_scratch;
+  DeviceBuffer stage_in, stage_out, stage_ids;
+  std::mutex mu;
+  Timing timing;
+
+  const double2* fbsk() const { return (const double2*)blob; }
+  const void* ksk() const { return (const char*)blob + fbsk_bytes; }
+  size_t big() const { return (size_t)p.glwe_dimension * p.polynomial_size; }
+  size_t glwe_words() const { return (size_t)(p.glwe_dimension + 1) * p.polynomial_size; }
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int validate_params(const camd_params& p) {
+  if (p.torus_bits != 32 && p.torus_bits != 64) return fail(CAMD_EINVAL, "torus_bits must be 32 or 64");
+  const uint32_t N = p.polynomial_size;
+  if (N < 256 || N > 16384 || (N & (N - 1))) return fail(CAMD_EINVAL, "polynomial_size must be a power of two in [256, 16384]");
+  if (p.lwe_dimension == 0 || p.glwe_dimension == 0 || p.glwe_dimension > 8) return fail(CAMD_EINVAL, "bad lwe/glwe dimension");
+  if (p.pbs_level == 0 || p.pbs_base_log == 0 || p.pbs_base_log * p.pbs_level >= p.torus_bits || p.pbs_base_log > 31)
+    return fail(CAMD_EINVAL, "bad bootstrap decomposition (need 0 < base_log*level < torus_bits, base_log <= 31)");
+  if (p.ks_level == 0 || p.ks_level > 8 || p.ks_base_log == 0 || p.ks_base_log * p.ks_level >= p.torus_bits || p.ks_base_log > 31)
+    return fail(CAMD_EINVAL, "bad keyswitch decomposition (need 0 < base_log*level < torus_bits, level <= 8)");
+  return CAMD_OK;
+}
+
+size_t fbsk_bytes_of(const camd_params& p) {
+  return (size_t)p.lwe_dimension * p.pbs_level * (p.glwe_dimension + 1) * (p.glwe_dimension + 1) * (p.polynomial_size / 2) *
+         sizeof(double2);
+}
+size_t ksk_bytes_of(const camd_params& p) {
+  return (size_t)p.glwe_dimension * p.polynomial_size * p.ks_level * (p.lwe_dimension + 1) * (p.torus_bits / 8);
+}
+
+int pick_variant(const camd_params& p, int requested, int* out) {
+  if (requested == CAMD_PBS_GENERIC) { *out = CAMD_PBS_GENERIC; return CAMD_OK; }
+  if (requested == CAMD_PBS_WAVE) {
+    if (!wave_supported(p)) return fail(CAMD_EINVAL, "the wave-per-polynomial kernel has no instance for this parameter set");
+    *out = CAMD_PBS_WAVE;
+    return CAMD_OK;
+  }
+  if (requested != CAMD_PBS_AUTO) return fail(CAMD_EINVAL, "unknown pbs_variant");
+  *out = wave_supported(p) ? CAMD_PBS_WAVE : CAMD_PBS_GENERIC;
+  return CAMD_OK;
+}
+
+// allocates blob + tables; leaves the Fourier key uninitialised
+int key_alloc(camd_context* ctx, const camd_params& p, int variant, camd_server_key** out) {
+  camd_server_key* key = new (std::nothrow) camd_server_key();
+  if (!key) return fail(CAMD_ENOMEM, "out of host memory");
+  key->ctx = ctx;
+  key->p = p;
+  key->variant = variant;
+  key->word = p.torus_bits / 8;
+  key->fbsk_bytes = fbsk_bytes_of(p);
+  key->ksk_bytes = ksk_bytes_of(p);
+  hipError_t e = hipMalloc(&key->blob, key->fbsk_bytes + key->ksk_bytes);
+  if (e != hipSuccess) {
+    delete key;
+    return fail(CAMD_ENOMEM, std::string("hipMalloc(key blob): ") + hipGetErrorString(e));
+  }
+  const size_t tcount = (variant == CAMD_PBS_WAVE) ? wave_tables_count(p.polynomial_size) : generic_tables_count(p.polynomial_size);
+  std::vector<double2> host(tcount);
+  if (variant == CAMD_PBS_WAVE) wave_fill_tables(p.polynomial_size, host.data());
+  else generic_fill_tables(p.polynomial_size, host.data());
+  e = hipMalloc((void**)&key->tables, tcount * sizeof(double2));
+  if (e == hipSuccess) e = hipMemcpy(key->tables, host.data(), tcount * sizeof(double2), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(key->blob);
+    if (key->tables) (void)hipFree(key->tables);
+    delete key;
+    return fail(CAMD_EHIP, std::string("twiddle table upload: ") + hipGetErrorString(e));
+  }
+  *out = key;
+  return CAMD_OK;
+}
+
+template <typename T>
+int key_fill(camd_server_key* key, const void* bsk_host, const void* ksk_host) {
+  const camd_params& p = key->p;
+  hipStream_t s = key->ctx->stream;
+  const size_t polys = (size_t)p.lwe_dimension * p.pbs_level * (p.glwe_dimension + 1) * (p.glwe_dimension + 1);
+  const size_t std_bytes = polys * p.polynomial_size * sizeof(T);
+  void* d_std = nullptr;
+  CAMD_HIP(hipMalloc(&d_std, std_bytes));
+  hipError_t e = hipMemcpyAsync(d_std, bsk_host, std_bytes, hipMemcpyHostToDevice, s);
+  int rc = CAMD_OK;
+  if (e != hipSuccess) rc = fail(CAMD_EHIP, std::string("bsk upload: ") + hipGetErrorString(e));
+  if (rc == CAMD_OK) {
+    if (key->variant == CAMD_PBS_WAVE) rc = wave_bsk_to_fourier<T>((const T*)d_std, (double2*)key->blob, key->tables, p, s);
+    else rc = generic_bsk_to_fourier<T>((const T*)d_std, (double2*)key->blob, key->tables, p.polynomial_size, polys, s);
+  }
+  if (rc == CAMD_OK) {
+    e = hipMemcpyAsync((char*)key->blob + key->fbsk_bytes, ksk_host, key->ksk_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = fail(CAMD_EHIP, std::string("ksk upload: ") + hipGetErrorString(e));
+  } else {
+    (void)hipStreamSynchronize(s);
+  }
+  (void)hipFree(d_std);
+  return rc;
+}
+
+void key_free(camd_server_key* key) {
+  if (!key) return;
+  key->timing.clear();
+  if (key->blob) (void)hipFree(key->blob);
+  if (key->tables) (void)hipFree(key->tables);
+  key->luts.release();
+  key->mid.release();
+  key->pbs_scratch.release();
+  key->stage_in.release();
+  key->stage_out.release();
+  key->stage_ids.release();
+  delete key;
+}
+
+int reserve_locked(camd_server_key* key, size_t count) {
+  const camd_params& p = key->p;
+  const size_t mid_words = std::max<size_t>(key->big() + 1, p.lwe_dimension + 1);
+  int rc = key->mid.ensure(count * mid_words * key->word);
+  if (rc != CAMD_OK) return rc;
+  if (key->variant == CAMD_PBS_GENERIC) {
+    unsigned grid = 1;
+    const size_t bytes = generic_scratch_bytes(p.glwe_dimension, p.polynomial_size, (int)key->word, &grid, count);
+    rc = key->pbs_scratch.ensure(bytes);
+  }
+  return rc;
+}
+
+struct TimedRegion {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>>* list = nullptr;
+  hipStream_t s = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  TimedRegion(camd_server_key* key, bool is_pbs, hipStream_t stream) {
+    if (!key->timing.enabled) return;
+    list = is_pbs ? &key->timing.pbs : &key->timing.ks;
+    s = stream;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { list = nullptr; return; }
+    (void)hipEventRecord(a, s);
+  }
+  ~TimedRegion() {
+    if (!list) return;
+    (void)hipEventRecord(b, s);
+    list->push_back({a, b});
+  }
+};
+
+template <typename T>
+int run_pbs(camd_server_key* key, const T* in, size_t in_stride, const uint32_t* ids, T* out, size_t out_stride,
+            size_t count, hipStream_t s) {
+  if (key->lut_count == 0) return fail(CAMD_EINVAL, "no look-up table uploaded for this key");
+  const camd_params& p = key->p;
+  PbsLaunch<T> a{};
+  a.ct_in = in; a.in_stride = in_stride; a.ct_out = out; a.out_stride = out_stride;
+  a.lut_ids = ids; a.luts = (const T*)key->luts.ptr; a.lut_count = key->lut_count; a.count = count;
+  a.fbsk = key->fbsk(); a.tables = key->tables; a.scratch = key->pbs_scratch.ptr;
+  a.n = p.lwe_dimension; a.k = p.glwe_dimension; a.N = p.polynomial_size; a.level = p.pbs_level; a.base_log = p.pbs_base_log;
+  TimedRegion t(key, true, s);
+  return key->variant == CAMD_PBS_WAVE ? wave_launch_pbs<T>(a, s) : generic_launch_pbs<T>(a, s);
+}
+
+template <typename T>
+int run_ks(camd_server_key* key, const T* in, size_t in_stride, T* out, size_t out_stride, size_t count, hipStream_t s) {
+  const camd_params& p = key->p;
+  TimedRegion t(key, false, s);
+  return launch_keyswitch<T>(in, in_stride, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
+                             p.ks_base_log, p.ks_level, count, s);
+}
+
+enum class Op { KsPbs, PbsKs, Pbs, Ks };
+
+size_t in_words(const camd_server_key* k, Op op) {
+  return (op == Op::KsPbs || op == Op::Ks) ? k->big() + 1 : (size_t)k->p.lwe_dimension + 1;
+}
+size_t out_words(const camd_server_key* k, Op op) {
+  return (op == Op::KsPbs || op == Op::Pbs) ? k->big() + 1 : (size_t)k->p.lwe_dimension + 1;
+}
+
+template <typename T>
+int run_op_device(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count, hipStream_t s) {
+  int rc = reserve_locked(key, count);
+  if (rc != CAMD_OK) return rc;
+  const size_t big1 = key->big() + 1, small1 = (size_t)key->p.lwe_dimension + 1;
+  switch (op) {
+    case Op::KsPbs:
+      rc = run_ks<T>(key, (const T*)in, big1, (T*)key->mid.ptr, small1, count, s);
+      if (rc == CAMD_OK) rc = run_pbs<T>(key, (const T*)key->mid.ptr, small1, ids, (T*)out, big1, count, s);
+      break;
+    case Op::PbsKs:
+      rc = run_pbs<T>(key, (const T*)in, small1, ids, (T*)key->mid.ptr, big1, count, s);
+      if (rc == CAMD_OK) rc = run_ks<T>(key, (const T*)key->mid.ptr, big1, (T*)out, small1, count, s);
+      break;
+    case Op::Pbs:
+      rc = run_pbs<T>(key, (const T*)in, small1, ids, (T*)out, big1, count, s);
+      break;
+    case Op::Ks:
+      rc = run_ks<T>(key, (const T*)in, big1, (T*)out, small1, count, s);
+      break;
+  }
+  return rc;
+}
+
+int dispatch_device(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count, void* stream) {
+  if (!key || (!in && count) || (!out && count)) return fail(CAMD_EINVAL, "null argument");
+  if (count == 0) return CAMD_OK;
+  DeviceGuard g(key->ctx->device);
+  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
+  hipStream_t s = (hipStream_t)stream;
+  return key->p.torus_bits == 64 ? run_op_device<uint64_t>(key, op, in, ids, out, count, s)
+                                 : run_op_device<uint32_t>(key, op, in, ids, out, count, s);
+}
+
+int dispatch_host(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count) {
+  if (!key || (!in && count) || (!out && count)) return fail(CAMD_EINVAL, "null argument");
+  if (count == 0) return CAMD_OK;
+  std::lock_guard<std::mutex> lock(key->mu);
+  DeviceGuard g(key->ctx->device);
+  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
+  hipStream_t s = key->ctx->stream;
+  const size_t ib = count * in_words(key, op) * key->word, ob = count * out_words(key, op) * key->word;
+  int rc = key->stage_in.ensure(ib);
+  if (rc == CAMD_OK) rc = key->stage_out.ensure(ob);
+  if (rc == CAMD_OK && ids) rc = key->stage_ids.ensure(count * sizeof(uint32_t));
+  if (rc != CAMD_OK) return rc;
+  if (ids) {
+    for (size_t i = 0; i < count; i++)
+      if (ids[i] >= key->lut_count) return fail(CAMD_EINVAL, "lut id out of range");
+    CAMD_HIP(hipMemcpyAsync(key->stage_ids.ptr, ids, count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  }
+  CAMD_HIP(hipMemcpyAsync(key->stage_in.ptr, in, ib, hipMemcpyHostToDevice, s));
+  const uint32_t* d_ids = ids ? (const uint32_t*)key->stage_ids.ptr : nullptr;
+  rc = key->p.torus_bits == 64 ? run_op_device<uint64_t>(key, op, key->stage_in.ptr, d_ids, key->stage_out.ptr, count, s)
+                               : run_op_device<uint32_t>(key, op, key->stage_in.ptr, d_ids, key->stage_out.ptr, count, s);
+  if (rc != CAMD_OK) {
+    (void)hipStreamSynchronize(s);
+    return rc;
+  }
+  CAMD_HIP(hipMemcpyAsync(out, key->stage_out.ptr, ob, hipMemcpyDeviceToHost, s));
+  CAMD_HIP(hipStreamSynchronize(s));
+  return CAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* camd_last_error(void) { return g_last_error.c_str(); }
+const char* camd_version(void) { return "concrete_amd 0.1 (gfx950)"; }
+
+int camd_context_create(int device_id, camd_context** out) {
+  if (!out) return fail(CAMD_EINVAL, "null out pointer");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return fail(CAMD_ENODEV, "no HIP device is visible");
+  if (device_id < 0 || device_id >= ndev) return fail(CAMD_EINVAL, "device id out of range");
+  hipDeviceProp_t prop;
+  CAMD_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(CAMD_ENODEV, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+  DeviceGuard g(device_id);
+  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
+  camd_context* ctx = new (std::nothrow) camd_context();
+  if (!ctx) return fail(CAMD_ENOMEM, "out of host memory");
+  ctx->device = device_id;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(CAMD_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  *out = ctx;
+  return CAMD_OK;
+}
+
+int camd_context_destroy(camd_context* ctx) {
+  if (!ctx) return CAMD_OK;
+  DeviceGuard g(ctx->device);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return CAMD_OK;
+}
+
+int camd_context_device(const camd_context* ctx, int* device_id) {
+  if (!ctx || !device_id) return fail(CAMD_EINVAL, "null argument");
+  *device_id = ctx->device;
+  return CAMD_OK;
+}
+
+int camd_context_synchronize(camd_context* ctx) {
+  if (!ctx) return fail(CAMD_EINVAL, "null context");
+  DeviceGuard g(ctx->device);
+  CAMD_HIP(hipDeviceSynchronize());
+  return CAMD_OK;
+}
+
+int camd_server_key_create(camd_context* ctx, const camd_params* params, const void* bsk_standard, const void* ksk,
+                           int pbs_variant, camd_server_key** out) {
+  if (!ctx || !params || !bsk_standard || !ksk || !out) return fail(CAMD_EINVAL, "null argument");
+  *out = nullptr;
+  int rc = validate_params(*params);
+  if (rc != CAMD_OK) return rc;
+  int variant = CAMD_PBS_GENERIC;
+  rc = pick_variant(*params, pbs_variant, &variant);
+  if (rc != CAMD_OK) return rc;
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
+  camd_server_key* key = nullptr;
+  rc = key_alloc(ctx, *params, variant, &key);
+  if (rc != CAMD_OK) return rc;
+  rc = params->torus_bits == 64 ? key_fill<uint64_t>(key, bsk_standard, ksk) : key_fill<uint32_t>(key, bsk_standard, ksk);
+  if (rc != CAMD_OK) {
+    key_free(key);
+    return rc;
+  }
+  *out = key;
+  return CAMD_OK;
+}
+
+int camd_server_key_destroy(camd_server_key* key) {
+  if (!key) return CAMD_OK;
+  DeviceGuard g(key->ctx->device);
+  (void)hipDeviceSynchronize();
+  key_free(key);
+  return CAMD_OK;
+}
+
+int camd_server_key_params(const camd_server_key* key, camd_params* out) {
+  if (!key || !out) return fail(CAMD_EINVAL, "null argument");
+  *out = key->p;
+  return CAMD_OK;
+}
+
+int camd_server_key_variant(const camd_server_key* key, int* variant) {
+  if (!key || !variant) return fail(CAMD_EINVAL, "null argument");
+  *variant = key->variant;
+  return CAMD_OK;
+}
+
+int camd_server_key_blob_size(const camd_server_key* key, size_t* bytes) {
+  if (!key || !bytes) return fail(CAMD_EINVAL, "null argument");
+  *bytes = key->fbsk_bytes + key->ksk_bytes;
+  return CAMD_OK;
+}
+
+int camd_server_key_export_blob(const camd_server_key* key, void* device_dst, void* stream) {
+  if (!key || !device_dst) return fail(CAMD_EINVAL, "null argument");
+  DeviceGuard g(key->ctx->device);
+  CAMD_HIP(hipMemcpyAsync(device_dst, key->blob, key->fbsk_bytes + key->ksk_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return CAMD_OK;
+}
+
+int camd_server_key_import_blob(camd_context* ctx, const camd_params* params, int pbs_variant, const void* device_src,
+                                size_t bytes, void* stream, camd_server_key** out) {
+  if (!ctx || !params || !device_src || !out) return fail(CAMD_EINVAL, "null argument");
+  *out = nullptr;
+  int rc = validate_params(*params);
+  if (rc != CAMD_OK) return rc;
+  int variant = CAMD_PBS_GENERIC;
+  rc = pick_variant(*params, pbs_variant, &variant);
+  if (rc != CAMD_OK) return rc;
+  if (bytes != fbsk_bytes_of(*params) + ksk_bytes_of(*params)) return fail(CAMD_EINVAL, "blob size does not match the parameter set");
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
+  camd_server_key* key = nullptr;
+  rc = key_alloc(ctx, *params, variant, &key);
+  if (rc != CAMD_OK) return rc;
+  hipError_t e = hipMemcpyAsync(key->blob, device_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) {
+    key_free(key);
+    return fail(CAMD_EHIP, std::string("blob copy: ") + hipGetErrorString(e));
+  }
+  *out = key;
+  return CAMD_OK;
+}
+
+int camd_lut_upload(camd_server_key* key, const void* glwe_host, uint32_t* lut_id) {
+  if (!key || !glwe_host || !lut_id) return fail(CAMD_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lock(key->mu);
+  DeviceGuard g(key->ctx->device);
+  const size_t one = key->glwe_words() * key->word;
+  const size_t need = (size_t)(key->lut_count + 1) * one;
+  if (need > key->luts.bytes) {
+    // grow geometrically, keeping the tables already uploaded
+    size_t cap = key->luts.bytes ? key->luts.bytes * 2 : one * 16;
+    while (cap < need) cap *= 2;
+    void* fresh = nullptr;
+    CAMD_HIP(hipDeviceSynchronize());
+    CAMD_HIP(hipMalloc(&fresh, cap));
+    if (key->lut_count) {
+      hipError_t e = hipMemcpy(fresh, key->luts.ptr, (size_t)key->lut_count * one, hipMemcpyDeviceToDevice);
+      if (e != hipSuccess) {
+        (void)hipFree(fresh);
+        return fail(CAMD_EHIP, std::string("lut copy: ") + hipGetErrorString(e));
+      }
+    }
+    key->luts.release();
+    key->luts.ptr = fresh;
+    key->luts.bytes = cap;
+  }
+  CAMD_HIP(hipMemcpy((char*)key->luts.ptr + (size_t)key->lut_count * one, glwe_host, one, hipMemcpyHostToDevice));
+  *lut_id = key->lut_count++;
+  return CAMD_OK;
+}
+
+int camd_lut_count(const camd_server_key* key, uint32_t* count) {
+  if (!key || !count) return fail(CAMD_EINVAL, "null argument");
+  *count = key->lut_count;
+  return CAMD_OK;
+}
+
+int camd_ks_pbs_batch(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out, size_t count) {
+  return dispatch_host(key, Op::KsPbs, ct_in, lut_ids, ct_out, count);
+}
+int camd_pbs_ks_batch(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out, size_t count) {
+  return dispatch_host(key, Op::PbsKs, ct_in, lut_ids, ct_out, count);
+}
+int camd_pbs_batch(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out, size_t count) {
+  return dispatch_host(key, Op::Pbs, ct_in, lut_ids, ct_out, count);
+}
+int camd_ks_batch(camd_server_key* key, const void* ct_in, void* ct_out, size_t count) {
+  return dispatch_host(key, Op::Ks, ct_in, nullptr, ct_out, count);
+}
+
+int camd_reserve(camd_server_key* key, size_t count) {
+  if (!key) return fail(CAMD_EINVAL, "null key");
+  std::lock_guard<std::mutex> lock(key->mu);
+  DeviceGuard g(key->ctx->device);
+  return reserve_locked(key, count);
+}
+int camd_ks_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out, size_t count,
+                             void* stream) {
+  return dispatch_device(key, Op::KsPbs, ct_in, lut_ids, ct_out, count, stream);
+}
+int camd_pbs_ks_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out, size_t count,
+                             void* stream) {
+  return dispatch_device(key, Op::PbsKs, ct_in, lut_ids, ct_out, count, stream);
+}
+int camd_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out, size_t count,
+                          void* stream) {
+  return dispatch_device(key, Op::Pbs, ct_in, lut_ids, ct_out, count, stream);
+}
+int camd_ks_batch_device(camd_server_key* key, const void* ct_in, void* ct_out, size_t count, void* stream) {
+  return dispatch_device(key, Op::Ks, ct_in, nullptr, ct_out, count, stream);
+}
+
+int camd_timing_enable(camd_server_key* key, int enable) {
+  if (!key) return fail(CAMD_EINVAL, "null key");
+  DeviceGuard g(key->ctx->device);
+  key->timing.clear();
+  key->timing.enabled = enable != 0;
+  return CAMD_OK;
+}
+
+int camd_timing_read(camd_server_key* key, double* pbs_ms_avg, uint64_t* pbs_launches, double* ks_ms_avg,
+                     uint64_t* ks_launches) {
+  if (!key) return fail(CAMD_EINVAL, "null key");
+  DeviceGuard g(key->ctx->device);
+  auto avg = [](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double* out_ms, uint64_t* out_n) -> int {
+    double total = 0;
+    uint64_t n = 0;
+    for (auto& e : v) {
+      CAMD_HIP(hipEventSynchronize(e.second));
+      float ms = 0;
+      CAMD_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+      total += ms;
+      n++;
+    }
+    if (out_ms) *out_ms = n ? total / (double)n : 0.0;
+    if (out_n) *out_n = n;
+    return CAMD_OK;
+  };
+  int rc = avg(key->timing.pbs, pbs_ms_avg, pbs_launches);
+  if (rc == CAMD_OK) rc = avg(key->timing.ks, ks_ms_avg, ks_launches);
+  key->timing.clear();
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// Launcher declarations shared by the C ABI layer and the kernel translation units.
+#pragma once
+
+#include "common.hpp"
+
+namespace camd {
+
+// Everything a bootstrap launch needs. Pointers are device memory.
+template <typename T>
+struct PbsLaunch {
+  const T* ct_in;            // [count][in_stride], n+1 words used
+  size_t in_stride;
+  T* ct_out;                 // [count][out_stride], kN+1 words written
+  size_t out_stride;
+  const uint32_t* lut_ids;   // [count] or nullptr (lut 0)
+  const T* luts;             // [lut_count][(k+1)*N]
+  uint32_t lut_count;
+  size_t count;
+  const double2* fbsk;       // Fourier bootstrap key in the layout of the kernel family
+  const double2* tables;     // twiddle tables of the kernel family
+  void* scratch;             // per-workgroup scratch (generic family only)
+  uint32_t n, k, N, level, base_log;
+};
+
+// ---- keyswitch (keyswitch.hip) ----
+template <typename T>
+int launch_keyswitch(const T* ct_in, size_t in_stride, T* ct_out, size_t out_stride, const T* ksk,
+                     uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level, size_t count,
+                     hipStream_t stream);
+
+// ---- workgroup-per-ciphertext bootstrap, any parameter set (pbs_generic.hip) ----
+// tables: twist[M] then stage twiddles W_M^j for j < M/2 (host fills them in double precision)
+size_t generic_tables_count(uint32_t N);                    // number of double2 entries
+void generic_fill_tables(uint32_t N, double2* host_tables);
+size_t generic_scratch_bytes(uint32_t k, uint32_t N, int torus_bytes, unsigned* grid_out, size_t count);
+template <typename T>
+int generic_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, uint32_t N, size_t polys,
+                           hipStream_t stream);
+template <typename T>
+int generic_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
+
+// ---- wave-per-polynomial bootstrap for N in {512, 1024, 2048} (pbs_wave.hip) ----
+bool wave_supported(const camd_params& p);
+size_t wave_tables_count(uint32_t N);
+void wave_fill_tables(uint32_t N, double2* host_tables);
+template <typename T>
+int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, const camd_params& p,
+                        hipStream_t stream);
+template <typename T>
+int wave_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
+
+}  // namespace camd

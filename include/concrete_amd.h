@@ -1,0 +1,149 @@
+/*
+ * concrete_amd — C ABI of the MI355X (gfx950) keyswitch + programmable-bootstrap backend.
+ *
+ * The reference (ryan-levatel/concrete) has no FFI for this path: its boundary is the Rust
+ * interface of concrete-core engines called from concrete-shortint and concrete-boolean.
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative CAMD_E* code on failure; it never
+ *     throws, aborts or prints. camd_last_error() returns the calling thread's last message.
+ *   - "host" entry points take host pointers (pageable or pinned), block until the result is
+ *     in the output buffer, and may be called concurrently on one key (calls are serialised
+ *     per key). "device" entry points take device pointers on the key's GPU plus a
+ *     hipStream_t (as void*, NULL = the default stream), enqueue the kernels and return
+ *     without synchronising.
+ *   - LWE ciphertexts are dim+1 torus words, body last. GLWE ciphertexts (look-up tables) are
+ *     (k+1)*N words, mask polynomials first, body polynomial last.
+ *   - standard bootstrap key layout: [n][level][k+1 rows][k+1 cols][N] words, level 1
+ *     (coarsest, q/B) first. keyswitch key layout: [kN][level][n+1] words, level 1 first.
+ *   - the torus word is uint64_t for shortint parameter sets and uint32_t for boolean ones.
+ */
+#ifndef CONCRETE_AMD_H
+#define CONCRETE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAMD_OK 0
+#define CAMD_EINVAL (-1)   /* bad argument (null pointer, unsupported parameter set, bad id) */
+#define CAMD_EHIP (-2)     /* a HIP runtime call failed; message holds hipGetErrorString */
+#define CAMD_ENOMEM (-3)   /* host or device allocation failed */
+#define CAMD_ENODEV (-4)   /* no usable gfx950 device */
+
+typedef struct camd_context camd_context;
+typedef struct camd_server_key camd_server_key;
+
+/* The cryptographic shape of a server key.
+ * shortint: concrete-shortint/src/parameters/mod.rs:28-45; boolean:
+ * concrete-boolean/src/parameters/mod.rs:30-41. torus_bits is 64 or 32. */
+typedef struct camd_params {
+  uint32_t lwe_dimension;   /* n */
+  uint32_t glwe_dimension;  /* k */
+  uint32_t polynomial_size; /* N, power of two, 256..16384 */
+  uint32_t pbs_base_log;
+  uint32_t pbs_level;
+  uint32_t ks_base_log;
+  uint32_t ks_level;
+  uint32_t torus_bits;
+} camd_params;
+
+/* Bootstrap kernel family. AUTO picks the wave-per-polynomial kernel when the parameter set
+ * has one and the workgroup-per-ciphertext kernel otherwise. */
+#define CAMD_PBS_AUTO 0
+#define CAMD_PBS_GENERIC 1
+#define CAMD_PBS_WAVE 2
+
+const char* camd_last_error(void);
+/* library version string */
+const char* camd_version(void);
+
+/* One context per (process, GPU). Replaces the per-thread engine objects
+ * (concrete-shortint/src/engine/mod.rs:88-128; concrete-boolean/src/engine/bootstrapping/cuda.rs:102-121). */
+int camd_context_create(int device_id, camd_context** out);
+int camd_context_destroy(camd_context* ctx);
+int camd_context_device(const camd_context* ctx, int* device_id);
+int camd_context_synchronize(camd_context* ctx);
+
+/* Server key creation from the STANDARD-domain bootstrap key and the keyswitch key (host
+ * pointers, copied; the caller keeps ownership). The forward negacyclic FFT of every
+ * bootstrap-key polynomial runs on the GPU. Replaces
+ * concrete-shortint/src/engine/server_side/mod.rs:47-50 (convert_lwe_bootstrap_key) and
+ * concrete-boolean/src/engine/bootstrapping/cuda.rs:123-137 (device key from the CPU key). */
+int camd_server_key_create(camd_context* ctx, const camd_params* params, const void* bsk_standard,
+                           const void* ksk, int pbs_variant, camd_server_key** out);
+int camd_server_key_destroy(camd_server_key* key);
+int camd_server_key_params(const camd_server_key* key, camd_params* out);
+/* which bootstrap kernel family the key uses (CAMD_PBS_GENERIC or CAMD_PBS_WAVE) */
+int camd_server_key_variant(const camd_server_key* key, int* variant);
+
+/* Device-resident key material as one blob (Fourier bootstrap key, keyswitch key), so that a
+ * key built on one GPU can be replicated to others with one broadcast and no second FFT.
+ * export copies the blob into `device_dst` (device pointer, >= blob size) on `stream`;
+ * import builds a key around a copy of `device_src`. The variant and params must match. */
+int camd_server_key_blob_size(const camd_server_key* key, size_t* bytes);
+int camd_server_key_export_blob(const camd_server_key* key, void* device_dst, void* stream);
+int camd_server_key_import_blob(camd_context* ctx, const camd_params* params, int pbs_variant,
+                                const void* device_src, size_t bytes, void* stream,
+                                camd_server_key** out);
+
+/* Look-up tables ("accumulators"): trivial GLWE ciphertexts of (k+1)*N words built by the
+ * caller (concrete-shortint/src/engine/mod.rs:130-178; boolean cpu.rs:49-53). Uploaded once
+ * and addressed by id afterwards; ids are dense, starting at 0. */
+int camd_lut_upload(camd_server_key* key, const void* glwe_host, uint32_t* lut_id);
+int camd_lut_count(const camd_server_key* key, uint32_t* count);
+
+/* ---- host-pointer batch entry points (blocking) ---- */
+
+/* shortint order, keyswitch then bootstrap: replaces
+ * ShortintEngine::programmable_bootstrap_keyswitch_assign and keyswitch_bootstrap_assign
+ * (concrete-shortint/src/engine/server_side/mod.rs:131-155, :95-118), batched.
+ * ct_in/ct_out: [count][kN+1] words, may alias. lut_ids: [count] or NULL (all use lut 0). */
+int camd_ks_pbs_batch(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out,
+                      size_t count);
+/* boolean order, bootstrap then keyswitch: replaces Bootstrapper::bootstrap_keyswitch
+ * (concrete-boolean/src/engine/bootstrapping/mod.rs:41-47, cpu.rs:215-259), batched.
+ * ct_in/ct_out: [count][n+1] words, may alias. */
+int camd_pbs_ks_batch(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out,
+                      size_t count);
+/* bootstrap only: replaces FftEngine::discard_bootstrap_lwe_ciphertext as called at
+ * server_side/mod.rs:148-153 and Bootstrapper::bootstrap (bootstrapping/mod.rs:27-31).
+ * ct_in: [count][n+1]; ct_out: [count][kN+1]. */
+int camd_pbs_batch(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out,
+                   size_t count);
+/* keyswitch only: replaces DefaultEngine::discard_keyswitch_lwe_ciphertext as called at
+ * server_side/mod.rs:141-145 and Bootstrapper::keyswitch (bootstrapping/mod.rs:33-39).
+ * ct_in: [count][kN+1]; ct_out: [count][n+1]. */
+int camd_ks_batch(camd_server_key* key, const void* ct_in, void* ct_out, size_t count);
+
+/* ---- device-pointer batch entry points (asynchronous on `stream`) ----
+ * Same semantics; pointers are device memory on the key's GPU. lut_ids is a device pointer or
+ * NULL. Scratch is owned by the key and grown on demand (growth synchronises the device);
+ * camd_reserve sizes it ahead of time for `count` ciphertexts. Calls on one key must be
+ * issued from one thread at a time and on one stream at a time. */
+int camd_reserve(camd_server_key* key, size_t count);
+int camd_ks_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,
+                             void* ct_out, size_t count, void* stream);
+int camd_pbs_ks_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,
+                             void* ct_out, size_t count, void* stream);
+int camd_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,
+                          void* ct_out, size_t count, void* stream);
+int camd_ks_batch_device(camd_server_key* key, const void* ct_in, void* ct_out, size_t count,
+                         void* stream);
+
+/* ---- measurement helpers ----
+ * Average device time in milliseconds of the bootstrap kernel (and of the keyswitch kernel)
+ * over the launches made since the last reset, taken with HIP events on the stream the
+ * kernels were launched on. Timing is off by default (enable != 0 turns it on). */
+int camd_timing_enable(camd_server_key* key, int enable);
+int camd_timing_read(camd_server_key* key, double* pbs_ms_avg, uint64_t* pbs_launches,
+                     double* ks_ms_avg, uint64_t* ks_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
