@@ -1,15 +1,385 @@
-// placeholder until the wave-per-polynomial family lands
+// Programmable bootstrap, wave-per-ciphertext family (N = 1024).
+//
+// Replaces FftEngine::discard_bootstrap_lwe_ciphertext as the reference calls it at
+// concrete-shortint/src/engine/server_side/mod.rs:148-153 (see pbs_generic.hip for the list of
+// steps). This is the throughput kernel for the PARAM_MESSAGE_*_CARRY_* sets with N = 1024.
+//
+// Design for CDNA4
+//   * ONE 64-lane wave owns one ciphertext for all n CMUX iterations; a 256-thread workgroup
+//     is four independent ciphertexts, one per SIMD. A wave never waits for another wave:
+//     the only workgroup barrier is after the twiddle tables are staged into LDS.
+//   * The accumulator (k+1 polynomials) lives in that wave's LDS slab; rotation by X^a is an
+//     index/sign permutation folded into the LDS read that feeds the decomposition.
+//   * The N/2-point complex FFT is 8 x 8 x 8: each lane holds 8 points in registers, does a
+//     radix-8 butterfly, and exchanges with the other lanes through a padded, bank-conflict-
+//     free LDS image (two exchanges per transform). Forward is decimation in frequency,
+//     inverse is decimation in time on the permuted spectrum, so no reordering pass exists;
+//     the Fourier bootstrap key is stored in exactly the (register, lane) order the
+//     multiply-accumulate consumes, which makes every key load a coalesced 1 KiB access.
+//   * The 1/(N/2) of the inverse transform is folded into the key at conversion time.
+//   * f64 -> torus rounding uses two magic-constant additions instead of conversions.
+//   * Rows of the GGSW are consumed as soon as their transform is ready; the Fourier-domain
+//     sums for the k+1 output polynomials stay in registers.
+#include <cmath>
+
 #include "kernels.hpp"
+
 namespace camd {
-bool wave_supported(const camd_params&) { return false; }
-size_t wave_tables_count(uint32_t) { return 1; }
-void wave_fill_tables(uint32_t, double2* t) { t[0] = make_double2(0, 0); }
+
+namespace {
+
+constexpr int WAVES = 4;          // ciphertexts per workgroup
+constexpr int RADIX = 8;          // points per lane (N = 1024)
+constexpr int ROW = 72;           // padded row of the exchange image, in doubles
+constexpr int PLANE = RADIX * ROW;
+
+// table layout, in double2 entries
+constexpr int TAB_TWIST = 0;                   // [a][lane]  e^{+i pi (64a+lane)/N}
+constexpr int TAB_TW0 = 512;                   // [b-1][lane] e^{-2 pi i lane b / 512}, b = 1..7
+constexpr int TAB_TW1 = TAB_TW0 + 7 * 64;      // [b-1][m]    e^{-2 pi i m b / 64},    b = 1..7, m < 8
+constexpr int TAB_COUNT = TAB_TW1 + 7 * 8;
+
+constexpr double HALF_SQRT2 = 0.70710678118654752440;
+
+__device__ __forceinline__ double2 mul_neg_i(double2 v) { return make_double2(v.y, -v.x); }
+__device__ __forceinline__ double2 mul_pos_i(double2 v) { return make_double2(-v.y, v.x); }
+
+// 8-point DFT in registers, natural order in and out. INV selects e^{+2 pi i jk/8}.
+template <bool INV>
+__device__ __forceinline__ void dft8(double2 (&x)[8]) {
+  const double2 a0 = cadd(x[0], x[4]), a4 = csub(x[0], x[4]);
+  const double2 a1 = cadd(x[1], x[5]), d5 = csub(x[1], x[5]);
+  const double2 a2 = cadd(x[2], x[6]), d6 = csub(x[2], x[6]);
+  const double2 a3 = cadd(x[3], x[7]), d7 = csub(x[3], x[7]);
+  double2 a5, a6, a7;
+  if (!INV) {
+    a5 = make_double2((d5.x + d5.y) * HALF_SQRT2, (d5.y - d5.x) * HALF_SQRT2);
+    a6 = mul_neg_i(d6);
+    a7 = make_double2((d7.y - d7.x) * HALF_SQRT2, -(d7.x + d7.y) * HALF_SQRT2);
+  } else {
+    a5 = make_double2((d5.x - d5.y) * HALF_SQRT2, (d5.x + d5.y) * HALF_SQRT2);
+    a6 = mul_pos_i(d6);
+    a7 = make_double2(-(d7.x + d7.y) * HALF_SQRT2, (d7.x - d7.y) * HALF_SQRT2);
+  }
+  const double2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
+  const double2 b1 = cadd(a1, a3), e3 = csub(a1, a3);
+  const double2 b4 = cadd(a4, a6), b6 = csub(a4, a6);
+  const double2 b5 = cadd(a5, a7), e7 = csub(a5, a7);
+  const double2 b3 = INV ? mul_pos_i(e3) : mul_neg_i(e3);
+  const double2 b7 = INV ? mul_pos_i(e7) : mul_neg_i(e7);
+  x[0] = cadd(b0, b1);
+  x[4] = csub(b0, b1);
+  x[2] = cadd(b2, b3);
+  x[6] = csub(b2, b3);
+  x[1] = cadd(b4, b5);
+  x[5] = csub(b4, b5);
+  x[3] = cadd(b6, b7);
+  x[7] = csub(b6, b7);
+}
+
+// Forward transform of 512 points held as x[a] = point 64a + lane.
+// Result: x[g] = X[64 g + 8 (lane & 7) + (lane >> 3)].
+__device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const double2* tab, double* sre,
+                                               double* sim) {
+  const int hi = lane >> 3, lo = lane & 7;
+  dft8<false>(x);
+#pragma unroll
+  for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
+  // exchange 1: register index b <-> lane bits 5:3
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    sre[b * ROW + lane] = x[b].x;
+    sim[b * ROW + lane] = x[b].y;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int idx = hi * ROW + q * 8 + lo;
+    x[q] = make_double2(sre[idx], sim[idx]);
+  }
+  dft8<false>(x);
+#pragma unroll
+  for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW1 + (b - 1) * 8 + lo]);
+  // exchange 2: register index b' <-> lane bits 2:0 (XOR keeps both sides conflict-free)
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    const int idx = hi * ROW + b * 8 + (lo ^ b);
+    sre[idx] = x[b].x;
+    sim[idx] = x[b].y;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int idx = hi * ROW + lo * 8 + (q ^ lo);
+    x[q] = make_double2(sre[idx], sim[idx]);
+  }
+  dft8<false>(x);
+}
+
+// Unnormalised inverse of fft512_forward: spectrum in, x[a] = 512 * point (64a + lane) out.
+__device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const double2* tab, double* sre,
+                                               double* sim) {
+  const int hi = lane >> 3, lo = lane & 7;
+  dft8<true>(x);
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int idx = hi * ROW + lo * 8 + (q ^ lo);
+    sre[idx] = x[q].x;
+    sim[idx] = x[q].y;
+  }
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    const int idx = hi * ROW + b * 8 + (lo ^ b);
+    x[b] = make_double2(sre[idx], sim[idx]);
+  }
+#pragma unroll
+  for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW1 + (b - 1) * 8 + lo]);
+  dft8<true>(x);
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int idx = hi * ROW + q * 8 + lo;
+    sre[idx] = x[q].x;
+    sim[idx] = x[q].y;
+  }
+#pragma unroll
+  for (int b = 0; b < 8; b++) x[b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
+#pragma unroll
+  for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
+  dft8<true>(x);
+}
+
+// f64 (torus units) -> torus word by magic-constant additions: adding 1.5*2^20 leaves
+// round(fr*2^32) in the low dword of the sum; the remainder, added to 1.5*2^-12, leaves
+// round(rem*2^64) in its mantissa. Round-to-nearest-even; +1/2 and -1/2 give the same word.
 template <typename T>
-int wave_bsk_to_fourier(const T*, double2*, const double2*, const camd_params&, hipStream_t) { return fail(CAMD_EINVAL, "no wave kernel"); }
+__device__ __forceinline__ T from_torus_fast(double t);
+template <>
+__device__ __forceinline__ uint64_t from_torus_fast<uint64_t>(double t) {
+  const double fr = t - rint(t);
+  const double a = fr + 0x1.8p20;
+  const uint32_t q = (uint32_t)__double2loint(a);
+  const double rem = fr - (a - 0x1.8p20);
+  const double b = rem + 0x1.8p-12;
+  const uint32_t lo = (uint32_t)__double2loint(b);
+  const uint32_t hi = q + (uint32_t)((__double2hiint(b) & 0xFFFFF) - 0x80000);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <>
+__device__ __forceinline__ uint32_t from_torus_fast<uint32_t>(double t) {
+  const double fr = t - rint(t);
+  return (uint32_t)__double2loint(fr + 0x1.8p20);
+}
+
+// broadcast lane 0's value through SGPRs so that the compiler sees a wave-uniform value
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <typename T, int K>
+constexpr size_t wave_slab_bytes() {
+  return (size_t)(K + 1) * 1024 * sizeof(T) + 2 * PLANE * sizeof(double);
+}
+template <typename T, int K>
+constexpr size_t wave_lds_bytes() {
+  return TAB_COUNT * sizeof(double2) + WAVES * wave_slab_bytes<T, K>();
+}
+
+// ---- key conversion: one wave per polynomial, same transform, key pre-scaled by 1/512 ----
 template <typename T>
-int wave_launch_pbs(const PbsLaunch<T>&, hipStream_t) { return fail(CAMD_EINVAL, "no wave kernel"); }
+__global__ __launch_bounds__(256) void wave_bsk_fourier_kernel(const T* __restrict__ bsk, double2* __restrict__ out,
+                                                               const double2* __restrict__ tables, size_t polys) {
+  using S = typename Torus<T>::Signed;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = tables[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t q = (size_t)blockIdx.x * WAVES + wave;
+  if (q >= polys) return;
+  double* sre = (double*)(smem + TAB_COUNT * sizeof(double2)) + (size_t)wave * 2 * PLANE;
+  double* sim = sre + PLANE;
+  const T* poly = bsk + q * 1024;
+  const double scale = (Torus<T>::BITS == 64) ? 0x1.0p-64 : 0x1.0p-32;
+  double2 x[8];
+#pragma unroll
+  for (int a = 0; a < 8; a++) {
+    const int j = 64 * a + lane;
+    const double re = signed_to_double((S)poly[j]) * scale;
+    const double im = signed_to_double((S)poly[j + 512]) * scale;
+    x[a] = cmul(make_double2(re, im), tab[TAB_TWIST + j]);
+  }
+  fft512_forward(x, lane, tab, sre, sim);
+  double2* dst = out + q * 512;
+#pragma unroll
+  for (int g = 0; g < 8; g++) dst[g * 64 + lane] = make_double2(x[g].x * (1.0 / 512.0), x[g].y * (1.0 / 512.0));
+}
+
+// ---- the bootstrap ----
+template <typename T, int K, int L, int BL>
+__global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
+  using S = typename Torus<T>::Signed;
+  constexpr int N = 1024, M = 512, LOGN = 10;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = a.tables[t];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t ct = (size_t)blockIdx.x * WAVES + wave;
+  if (ct >= a.count) return;
+
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
+  T* ct0 = (T*)slab;
+  double* sre = (double*)(slab + (size_t)(K + 1) * N * sizeof(T));
+  double* sim = sre + PLANE;
+
+  const T* in = a.ct_in + ct * a.in_stride;
+  const uint32_t n = a.n;
+  const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
+  const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * ((K + 1) * N);
+
+  // ct0 <- lut * X^{-b_hat}
+  {
+    const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+    const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+    for (int idx = lane; idx < (K + 1) * N; idx += 64) {
+      const int c = idx >> LOGN, j = idx & (N - 1);
+      ct0[idx] = rotated_coeff<T>(lut + (size_t)c * N, j, d0, N);
+    }
+  }
+
+  T a_next = in[0];
+  for (uint32_t i = 0; i < n; i++) {
+    const T ai = wave_uniform(a_next);
+    a_next = in[i + 1];  // in[n] is the body: always readable
+    if (ai == 0) continue;
+    const uint32_t a_hat = modswitch<T>(ai, LOGN) & (2 * N - 1);
+
+    double2 acc[K + 1][8];
+#pragma unroll
+    for (int r = 0; r <= K; r++) {
+      // gather rotated - own, start the decomposition
+      const T* p = ct0 + r * N;
+      T st0[8], st1[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+        const T x0 = rotated_coeff<T>(p, j0, a_hat, N) - p[j0];
+        const T x1 = rotated_coeff<T>(p, j1, a_hat, N) - p[j1];
+        st0[q] = decomp_init_state<T>(x0, BL, L);
+        st1[q] = decomp_init_state<T>(x1, BL, L);
+      }
+#pragma unroll
+      for (int l = L; l >= 1; l--) {
+        const double2* brow = a.fbsk + ((((size_t)i * L + (l - 1)) * (K + 1) + r) * (K + 1)) * M + lane;
+        double2 x[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const S g0 = decomp_next<T>(st0[q], BL), g1 = decomp_next<T>(st1[q], BL);
+          x[q] = cmul(make_double2((double)(int32_t)g0, (double)(int32_t)g1), tab[TAB_TWIST + 64 * q + lane]);
+        }
+        fft512_forward(x, lane, tab, sre, sim);
+#pragma unroll
+        for (int c = 0; c <= K; c++) {
+#pragma unroll
+          for (int g = 0; g < 8; g++) {
+            const double2 w = brow[(size_t)c * M + g * 64];
+            acc[c][g] = (r == 0 && l == L) ? cmul(w, x[g]) : cfma(w, x[g], acc[c][g]);
+          }
+        }
+      }
+    }
+
+#pragma unroll
+    for (int c = 0; c <= K; c++) {
+      fft512_inverse(acc[c], lane, tab, sre, sim);
+      T* p = ct0 + c * N;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t j0 = 64 * q + lane;
+        const double2 v = cmul_conj(acc[c][q], tab[TAB_TWIST + j0]);
+        p[j0] += from_torus_fast<T>(v.x);
+        p[j0 + M] += from_torus_fast<T>(v.y);
+      }
+    }
+  }
+
+  // sample extraction of coefficient 0
+  T* out = a.ct_out + ct * a.out_stride;
+  for (int idx = lane; idx < K * N; idx += 64) {
+    const int c = idx >> LOGN, j = idx & (N - 1);
+    const T* p = ct0 + c * N;
+    out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
+  }
+  if (lane == 0) out[K * N] = ct0[K * N];
+}
+
+template <typename T, int K, int L, int BL>
+int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
+  constexpr size_t lds = wave_lds_bytes<T, K>();
+  static_assert(lds <= 160 * 1024, "LDS budget exceeded");
+  auto kern = wave_pbs_kernel<T, K, L, BL>;
+  CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+  CAMD_HIP(hipGetLastError());
+  return CAMD_OK;
+}
+
+}  // namespace
+
+bool wave_supported(const camd_params& p) {
+  if (p.polynomial_size != 1024) return false;
+  if (p.torus_bits == 64 && p.glwe_dimension == 2 && p.pbs_level == 1 && p.pbs_base_log == 23) return true;
+  return false;
+}
+
+size_t wave_tables_count(uint32_t) { return TAB_COUNT; }
+
+void wave_fill_tables(uint32_t N, double2* t) {
+  for (int j = 0; j < 512; j++) {
+    const double ang = M_PI * (double)j / (double)N;
+    t[TAB_TWIST + j] = make_double2(std::cos(ang), std::sin(ang));
+  }
+  for (int b = 1; b < 8; b++)
+    for (int m = 0; m < 64; m++) {
+      const double ang = -2.0 * M_PI * (double)(m * b) / 512.0;
+      t[TAB_TW0 + (b - 1) * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+  for (int b = 1; b < 8; b++)
+    for (int m = 0; m < 8; m++) {
+      const double ang = -2.0 * M_PI * (double)(m * b) / 64.0;
+      t[TAB_TW1 + (b - 1) * 8 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+}
+
+template <typename T>
+int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, const camd_params& p,
+                        hipStream_t stream) {
+  if (!wave_supported(p)) return fail(CAMD_EINVAL, "wave kernel: unsupported parameter set");
+  const size_t polys = (size_t)p.lwe_dimension * p.pbs_level * (p.glwe_dimension + 1) * (p.glwe_dimension + 1);
+  const size_t lds = TAB_COUNT * sizeof(double2) + WAVES * 2 * PLANE * sizeof(double);
+  hipLaunchKernelGGL(wave_bsk_fourier_kernel<T>, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds, stream,
+                     bsk_std, fbsk, tables, polys);
+  CAMD_HIP(hipGetLastError());
+  return CAMD_OK;
+}
+
+template <typename T>
+int wave_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
+  if (a.count == 0) return CAMD_OK;
+  if constexpr (sizeof(T) == 8) {
+    if (a.N == 1024 && a.k == 2 && a.level == 1 && a.base_log == 23) return launch_instance<T, 2, 1, 23>(a, stream);
+  }
+  return fail(CAMD_EINVAL, "wave kernel: no instance for this parameter set");
+}
+
 template int wave_bsk_to_fourier<uint64_t>(const uint64_t*, double2*, const double2*, const camd_params&, hipStream_t);
 template int wave_bsk_to_fourier<uint32_t>(const uint32_t*, double2*, const double2*, const camd_params&, hipStream_t);
 template int wave_launch_pbs<uint64_t>(const PbsLaunch<uint64_t>&, hipStream_t);
 template int wave_launch_pbs<uint32_t>(const PbsLaunch<uint32_t>&, hipStream_t);
-}
+
+}  // namespace camd

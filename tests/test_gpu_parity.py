@@ -44,7 +44,7 @@ def encrypt_batch(ks, msgs):
     return np.stack([ks.o.lwe_encrypt(ks.rng, ks.glwe, int(m) * delta, ks.lwe_std) for m in msgs])
 
 
-@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC])
+@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC, CAMD_PBS_WAVE])
 def test_keyswitch_bit_exact_2_2(gpu_ctx, keys_2_2, variant):
     ks = keys_2_2
     dk = make_device_key(gpu_ctx, ks, variant)
@@ -58,7 +58,7 @@ def test_keyswitch_bit_exact_2_2(gpu_ctx, keys_2_2, variant):
     assert got.dtype == np.uint64 and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC])
+@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC, CAMD_PBS_WAVE])
 def test_trivial_bootstrap_bit_exact_2_2(gpu_ctx, keys_2_2, variant):
     """Mask = 0 skips every CMUX: the output is the rotated look-up table, sample-extracted."""
     ks = keys_2_2
@@ -78,7 +78,7 @@ def test_trivial_bootstrap_bit_exact_2_2(gpu_ctx, keys_2_2, variant):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC])
+@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC, CAMD_PBS_WAVE])
 def test_ks_pbs_parity_2_2(gpu_ctx, keys_2_2, variant):
     ks = keys_2_2
     p = ks.params
