@@ -251,16 +251,38 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
     }
   }
 
-  T a_next = in[0];
-  for (uint32_t i = 0; i < n; i++) {
-    const T ai = wave_uniform(a_next);
-    a_next = in[i + 1];  // in[n] is the body: always readable
-    if (ai == 0) continue;
-    const uint32_t a_hat = modswitch<T>(ai, LOGN) & (2 * N - 1);
-
-    double2 acc[K + 1][8];
+  // The (iteration, row) nest is flattened into one loop of steps so that the key rows of the
+  // next step are loaded at a single site: they are issued right after the multiply-accumulate
+  // of the current step and land while the inverse transforms / the next decomposition and
+  // forward transform run. Iterations whose mask element is zero are skipped, as the reference
+  // does; their rows are never loaded.
+  double2 bq[K + 1][8];
+  auto load_rows = [&](uint32_t it, int r, int l) {
+    const double2* brow = a.fbsk + ((((size_t)it * L + (l - 1)) * (K + 1) + r) * (K + 1)) * M + lane;
 #pragma unroll
-    for (int r = 0; r <= K; r++) {
+    for (int c = 0; c <= K; c++)
+#pragma unroll
+      for (int g = 0; g < 8; g++) bq[c][g] = brow[(size_t)c * M + g * 64];
+  };
+  double2 acc[K + 1][8];
+#pragma unroll
+  for (int c = 0; c <= K; c++)
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      acc[c][g] = make_double2(0.0, 0.0);
+      bq[c][g] = make_double2(0.0, 0.0);
+    }
+
+  uint32_t it = 0;
+  int r = 0;
+  T a_cur = wave_uniform(in[0]);
+  T a_nxt = in[n > 1 ? 1 : n];
+  bool run = (a_cur != 0);
+  if (run) load_rows(0, 0, L);
+
+  while (it < n) {
+    if (run) {
+      const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
       // gather rotated - own, start the decomposition
       const T* p = ct0 + r * N;
       T st0[8], st1[8];
@@ -274,7 +296,6 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
       }
 #pragma unroll
       for (int l = L; l >= 1; l--) {
-        const double2* brow = a.fbsk + ((((size_t)i * L + (l - 1)) * (K + 1) + r) * (K + 1)) * M + lane;
         double2 x[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -285,26 +306,52 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
         for (int c = 0; c <= K; c++) {
 #pragma unroll
-          for (int g = 0; g < 8; g++) {
-            const double2 w = brow[(size_t)c * M + g * 64];
-            acc[c][g] = (r == 0 && l == L) ? cmul(w, x[g]) : cfma(w, x[g], acc[c][g]);
-          }
+          for (int g = 0; g < 8; g++) acc[c][g] = cfma(bq[c][g], x[g], acc[c][g]);
         }
+        if (l > 1) load_rows(it, r, l - 1);
       }
     }
 
+    // which step comes next, and is it executed?
+    const bool last_row = (!run) || (r == K);
+    const bool finish = run && (r == K);
+    uint32_t it2 = it;
+    int r2 = r + 1;
+    T a2 = a_cur;
+    bool run2 = run;
+    if (last_row) {
+      it2 = it + 1;
+      r2 = 0;
+      a2 = wave_uniform(a_nxt);
+      run2 = (a2 != 0) && (it2 < n);
+      a_nxt = in[(it2 + 1 < n) ? it2 + 1 : n];
+    }
+    if (run2) load_rows(it2, r2, L);
+
+    if (finish) {
 #pragma unroll
-    for (int c = 0; c <= K; c++) {
-      fft512_inverse(acc[c], lane, tab, sre, sim);
-      T* p = ct0 + c * N;
+      for (int c = 0; c <= K; c++) {
+        double2 z[8];
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const uint32_t j0 = 64 * q + lane;
-        const double2 v = cmul_conj(acc[c][q], tab[TAB_TWIST + j0]);
-        p[j0] += from_torus_fast<T>(v.x);
-        p[j0 + M] += from_torus_fast<T>(v.y);
+        for (int g = 0; g < 8; g++) {
+          z[g] = acc[c][g];
+          acc[c][g] = make_double2(0.0, 0.0);
+        }
+        fft512_inverse(z, lane, tab, sre, sim);
+        T* pc = ct0 + c * N;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t j0 = 64 * q + lane;
+          const double2 v = cmul_conj(z[q], tab[TAB_TWIST + j0]);
+          pc[j0] += from_torus_fast<T>(v.x);
+          pc[j0 + M] += from_torus_fast<T>(v.y);
+        }
       }
     }
+    it = it2;
+    r = r2;
+    a_cur = a2;
+    run = run2;
   }
 
   // sample extraction of coefficient 0
