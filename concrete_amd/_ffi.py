@@ -66,6 +66,26 @@ SYMBOLS = {
                               C.POINTER(C.c_uint64)]),
 }
 
+
+
+class CamdRng(C.Structure):
+    _fields_ = [("s", C.c_uint64 * 4)]
+
+
+_RP = C.POINTER(CamdRng)
+_dbl, _u32, _u64 = C.c_double, C.c_uint32, C.c_uint64
+# every symbol include/concrete_amd_client.h declares
+SYMBOLS.update({
+    "camd_rng_seed": (None, [_RP, _u64]),
+    "camd_client_gen_binary_key": (_i, [_RP, _u32, _sz, _vp]),
+    "camd_client_gen_bootstrap_key": (_i, [_RP, _PP, _dbl, _vp, _vp, _vp, _i]),
+    "camd_client_gen_keyswitch_key": (_i, [_RP, _u32, _vp, _sz, _vp, _sz, _u32, _u32, _dbl, _vp]),
+    "camd_client_lwe_encrypt": (_i, [_RP, _u32, _vp, _sz, _vp, _sz, _dbl, _vp]),
+    "camd_client_lwe_phase": (_i, [_u32, _vp, _sz, _vp, _sz, _vp]),
+    "camd_client_shortint_accumulator": (_i, [_u32, _u32, _u32, _u32, _vp, _vp]),
+    "camd_client_boolean_accumulator": (_i, [_u32, _u32, _vp]),
+})
+
 _lib = None
 
 

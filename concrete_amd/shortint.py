@@ -1,0 +1,236 @@
+"""Host-side mirror of concrete-shortint's interface for the keyswitch + bootstrap path.
+
+Same names, argument meaning and error behaviour as the reference, with the computation on the
+GPU through the C ABI:
+
+* ``ClientKey``  — ``concrete-shortint/src/client_key/mod.rs`` + ``engine/client_side.rs:9-144``
+* ``ServerKey``  — ``concrete-shortint/src/server_key/mod.rs:54-229`` +
+  ``engine/server_side/mod.rs:22-311``
+* ``Ciphertext`` — ``concrete-shortint/src/ciphertext/mod.rs`` (LWE words, degree, moduli)
+
+What the reference does one ciphertext at a time with a thread-local engine is also offered in
+batched form (``*_batch``): many ciphertexts, one look-up table id each, one launch.
+Look-up tables are cached on the device by content, where the reference rebuilds them per call
+(``engine/server_side/mod.rs:205,231``).
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass
+from typing import Callable, Iterable, Sequence
+
+import numpy as np
+
+from . import client as _client
+from .backend import CAMD_PBS_AUTO, Context, DeviceServerKey
+
+
+@dataclass
+class Ciphertext:
+    """LWE ciphertext under the large key, with the reference's bookkeeping fields."""
+    ct: np.ndarray            # kN+1 uint64 words, body last
+    degree: int
+    message_modulus: int
+    carry_modulus: int
+
+    def clone(self) -> "Ciphertext":
+        return Ciphertext(self.ct.copy(), self.degree, self.message_modulus, self.carry_modulus)
+
+
+class LookupTable:
+    """A look-up table ("accumulator") resident on the GPU: trivial GLWE + its device id."""
+
+    def __init__(self, glwe: np.ndarray, lut_id: int):
+        self.glwe = glwe
+        self.lut_id = lut_id
+
+
+class ClientKey:
+    """Secret keys of one parameter set (engine/client_side.rs:9-31)."""
+
+    def __init__(self, parameters, seed: int = 0):
+        self.parameters = parameters
+        self._rng = _client.Rng(seed)
+        p = parameters
+        self.lwe_secret_key_after_ks = _client.gen_binary_key(self._rng, 64, p.lwe_dimension)
+        self.glwe_secret_key = _client.gen_binary_key(self._rng, 64, p.glwe_dimension * p.polynomial_size)
+        # transform_glwe_secret_key_to_lwe_secret_key: the flattened GLWE key
+        self.lwe_secret_key = self.glwe_secret_key
+
+    @classmethod
+    def new(cls, parameters, seed: int = 0) -> "ClientKey":
+        return cls(parameters, seed)
+
+    @property
+    def _delta(self) -> int:
+        p = self.parameters
+        return (1 << 63) // (p.message_modulus * p.carry_modulus)
+
+    def encrypt(self, message: int) -> Ciphertext:
+        return self.encrypt_with_message_modulus(message, self.parameters.message_modulus)
+
+    def encrypt_with_message_modulus(self, message: int, message_modulus: int) -> Ciphertext:
+        """engine/client_side.rs:45-83."""
+        p = self.parameters
+        carry_modulus = (p.message_modulus * p.carry_modulus) // message_modulus
+        m = int(message) % message_modulus
+        ct = _client.lwe_encrypt(self._rng, 64, self.lwe_secret_key, [m * self._delta], p.lwe_modular_std_dev)[0]
+        return Ciphertext(ct, message_modulus - 1, message_modulus, carry_modulus)
+
+    def unchecked_encrypt(self, message: int) -> Ciphertext:
+        """engine/client_side.rs:85-112: no reduction of the message."""
+        p = self.parameters
+        pt = (int(message) * self._delta) & 0xFFFFFFFFFFFFFFFF
+        ct = _client.lwe_encrypt(self._rng, 64, self.lwe_secret_key, [pt], p.lwe_modular_std_dev)[0]
+        return Ciphertext(ct, p.message_modulus * p.carry_modulus - 1, p.message_modulus, p.carry_modulus)
+
+    def encrypt_batch(self, messages: Iterable[int]) -> np.ndarray:
+        """Fresh encryptions of ``messages`` (reduced mod message_modulus) as a [count][kN+1] array."""
+        p = self.parameters
+        pts = [(int(m) % p.message_modulus) * self._delta for m in messages]
+        return _client.lwe_encrypt(self._rng, 64, self.lwe_secret_key, pts, p.lwe_modular_std_dev)
+
+    def decode(self, phase: int) -> int:
+        """Rounding of decrypt_message_and_carry (engine/client_side.rs:128-138)."""
+        delta = self._delta
+        rounding = (int(phase) & (delta >> 1)) << 1
+        return ((int(phase) + rounding) & 0xFFFFFFFFFFFFFFFF) // delta
+
+    def decrypt_message_and_carry(self, ct: Ciphertext) -> int:
+        return self.decode(_client.lwe_phase(64, self.lwe_secret_key, ct.ct)[0])
+
+    def decrypt(self, ct: Ciphertext) -> int:
+        return self.decrypt_message_and_carry(ct) % ct.message_modulus
+
+    def decrypt_message_and_carry_batch(self, cts: np.ndarray) -> np.ndarray:
+        phases = _client.lwe_phase(64, self.lwe_secret_key, cts)
+        return np.array([self.decode(int(ph)) for ph in phases], dtype=np.int64)
+
+
+class ServerKey:
+    """GPU-resident server key: keyswitch key + Fourier bootstrap key + moduli.
+
+    ``ServerKey.new(cks)`` follows engine/server_side/mod.rs:22-72: the bootstrap key is generated
+    in the standard domain, converted to the Fourier domain (here: on the GPU), and dropped.
+    """
+
+    def __init__(self, device_key: DeviceServerKey, parameters, max_degree: int | None = None):
+        self.key = device_key
+        self.parameters = parameters
+        self.message_modulus = parameters.message_modulus
+        self.carry_modulus = parameters.carry_modulus
+        self.max_degree = (parameters.message_modulus * parameters.carry_modulus - 1) if max_degree is None else max_degree
+        self._lut_cache: dict[bytes, LookupTable] = {}
+        # engine/mod.rs:195-199: the default accumulator is x -> x % message_modulus
+        msg = self.message_modulus
+        self._default_acc = self.generate_accumulator(lambda x: x % msg)
+
+    @classmethod
+    def new(cls, cks: ClientKey, ctx: Context | None = None, variant: int = CAMD_PBS_AUTO,
+            threads: int | None = None) -> "ServerKey":
+        p = cks.parameters
+        bsk = _client.gen_bootstrap_key(cks._rng, p, 64, cks.lwe_secret_key_after_ks, cks.glwe_secret_key, threads=threads)
+        ksk = _client.gen_keyswitch_key(cks._rng, p, 64, cks.lwe_secret_key, cks.lwe_secret_key_after_ks)
+        return cls.from_standard_keys(p, bsk, ksk, ctx=ctx, variant=variant)
+
+    @classmethod
+    def from_standard_keys(cls, parameters, bsk_standard: np.ndarray, ksk: np.ndarray, ctx: Context | None = None,
+                           variant: int = CAMD_PBS_AUTO) -> "ServerKey":
+        ctx = ctx or Context(0)
+        dk = DeviceServerKey.from_standard_keys(ctx, parameters, bsk_standard, ksk, variant=variant, torus_bits=64)
+        return cls(dk, parameters)
+
+    # ---- look-up tables ----
+    def generate_accumulator(self, f: Callable[[int], int]) -> LookupTable:
+        """server_key/mod.rs:119-126 -> engine/mod.rs:130-178, cached on the device by content."""
+        glwe = _client.shortint_accumulator(self.parameters, f)
+        digest = hashlib.blake2b(glwe.tobytes(), digest_size=16).digest()
+        lut = self._lut_cache.get(digest)
+        if lut is None:
+            lut = LookupTable(glwe, self.key.upload_lut(glwe))
+            self._lut_cache[digest] = lut
+        return lut
+
+    # ---- the path, one ciphertext (reference signatures) ----
+    def keyswitch_programmable_bootstrap(self, ct: Ciphertext, acc: LookupTable) -> Ciphertext:
+        """server_key/mod.rs:207-217 (clones, engine/server_side/mod.rs:120-129)."""
+        res = ct.clone()
+        self.keyswitch_programmable_bootstrap_assign(res, acc)
+        return res
+
+    def keyswitch_programmable_bootstrap_assign(self, ct: Ciphertext, acc: LookupTable) -> None:
+        """server_key/mod.rs:219-229 -> engine/server_side/mod.rs:131-155. Degree is not touched."""
+        ct.ct = self.key.ks_pbs(ct.ct[None, :], np.array([acc.lut_id], dtype=np.uint32))[0]
+
+    def keyswitch_bootstrap(self, ct: Ciphertext) -> Ciphertext:
+        """server_key/mod.rs:172-175 -> engine/server_side/mod.rs:85-118 (default accumulator)."""
+        return self.keyswitch_programmable_bootstrap(ct, self._default_acc)
+
+    def keyswitch_bootstrap_assign(self, ct: Ciphertext) -> None:
+        self.keyswitch_programmable_bootstrap_assign(ct, self._default_acc)
+
+    def carry_extract_assign(self, ct: Ciphertext) -> None:
+        """engine/server_side/mod.rs:198-212."""
+        modulus = ct.message_modulus
+        acc = self.generate_accumulator(lambda x: x // modulus)
+        self.keyswitch_programmable_bootstrap_assign(ct, acc)
+        ct.degree = min(modulus - 1, ct.degree // modulus)
+
+    def carry_extract(self, ct: Ciphertext) -> Ciphertext:
+        res = ct.clone()
+        self.carry_extract_assign(res)
+        return res
+
+    def message_extract_assign(self, ct: Ciphertext) -> None:
+        """engine/server_side/mod.rs:224-237."""
+        modulus = ct.message_modulus
+        acc = self.generate_accumulator(lambda x: x % modulus)
+        self.keyswitch_programmable_bootstrap_assign(ct, acc)
+        ct.degree = ct.message_modulus - 1
+
+    def message_extract(self, ct: Ciphertext) -> Ciphertext:
+        res = ct.clone()
+        self.message_extract_assign(res)
+        return res
+
+    def create_trivial(self, value: int) -> Ciphertext:
+        """engine/server_side/mod.rs:250-282: mask zero, sized with the bootstrap output dimension."""
+        p = self.parameters
+        modular_value = int(value) % self.message_modulus
+        delta = (1 << 63) // (self.message_modulus * self.carry_modulus)
+        ct = np.zeros(p.glwe_dimension * p.polynomial_size + 1, dtype=np.uint64)
+        ct[-1] = np.uint64(modular_value * delta)
+        return Ciphertext(ct, modular_value, self.message_modulus, self.carry_modulus)
+
+    # ---- leveled operations that feed the path (engine/server_side/{add,scalar_mul}.rs) ----
+    def unchecked_add_assign(self, lhs: Ciphertext, rhs: Ciphertext) -> None:
+        """engine/server_side/add.rs:17-26: wrapping add of the LWE words, degrees add."""
+        lhs.ct = lhs.ct + rhs.ct
+        lhs.degree += rhs.degree
+
+    def unchecked_scalar_mul_assign(self, ct: Ciphertext, scalar: int) -> None:
+        """engine/server_side/scalar_mul.rs:19-30."""
+        ct.ct = ct.ct * np.uint64(int(scalar) & 0xFF)
+        ct.degree *= int(scalar)
+
+    def unchecked_functional_bivariate_pbs(self, lhs: Ciphertext, rhs: Ciphertext, f: Callable[[int], int]) -> Ciphertext:
+        """engine/server_side/mod.rs:157-196: lhs*(deg_r+1) + rhs, then one bootstrap with f."""
+        res = lhs.clone()
+        modulus = rhs.degree + 1
+        self.unchecked_scalar_mul_assign(res, modulus)
+        self.unchecked_add_assign(res, rhs)
+        self.keyswitch_programmable_bootstrap_assign(res, self.generate_accumulator(f))
+        return res
+
+    # ---- batched forms ----
+    def keyswitch_programmable_bootstrap_batch(self, cts: np.ndarray, accs: Sequence[LookupTable] | LookupTable) -> np.ndarray:
+        """Many ciphertexts ([count][kN+1] uint64), one look-up table each (or one for all)."""
+        cts = np.ascontiguousarray(cts, dtype=np.uint64)
+        if isinstance(accs, LookupTable):
+            ids = np.full(cts.shape[0], accs.lut_id, dtype=np.uint32)
+        else:
+            ids = np.array([a.lut_id for a in accs], dtype=np.uint32)
+        return self.key.ks_pbs(cts, ids)
+
+    def keyswitch_bootstrap_batch(self, cts: np.ndarray) -> np.ndarray:
+        return self.keyswitch_programmable_bootstrap_batch(cts, self._default_acc)
