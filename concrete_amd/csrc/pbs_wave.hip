@@ -146,6 +146,14 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
   dft8<true>(x);
 }
 
+// wrapping add of a 64-bit (hi, lo) pair into a torus word, on the dword halves
+__device__ __forceinline__ uint64_t add_halves(uint64_t acc, uint32_t hi, uint32_t lo) {
+  const uint32_t alo = (uint32_t)acc, ahi = (uint32_t)(acc >> 32);
+  const uint32_t rlo = alo + lo;
+  const uint32_t rhi = ahi + hi + (rlo < lo ? 1u : 0u);
+  return ((uint64_t)rhi << 32) | rlo;
+}
+
 // f64 (torus units) -> torus word by magic-constant additions: adding 1.5*2^20 leaves
 // round(fr*2^32) in the low dword of the sum; the remainder, added to 1.5*2^-12, leaves
 // round(rem*2^64) in its mantissa. Round-to-nearest-even; +1/2 and -1/2 give the same word.
@@ -162,10 +170,55 @@ __device__ __forceinline__ uint64_t from_torus_fast<uint64_t>(double t) {
   const uint32_t hi = q + (uint32_t)((__double2hiint(b) & 0xFFFFF) - 0x80000);
   return ((uint64_t)hi << 32) | lo;
 }
+// acc += from_torus_fast(t), without assembling the 64-bit word first
+__device__ __forceinline__ uint64_t torus_accumulate(uint64_t acc, double t) {
+  const double fr = t - rint(t);
+  const double a = fr + 0x1.8p20;
+  const uint32_t q = (uint32_t)__double2loint(a);
+  const double rem = fr - (a - 0x1.8p20);
+  const double b = rem + 0x1.8p-12;
+  const uint32_t lo = (uint32_t)__double2loint(b);
+  const uint32_t hi = q + (uint32_t)((__double2hiint(b) & 0xFFFFF) - 0x80000);
+  return add_halves(acc, hi, lo);
+}
+__device__ __forceinline__ uint32_t torus_accumulate(uint32_t acc, double t) {
+  const double fr = t - rint(t);
+  return acc + (uint32_t)__double2loint(fr + 0x1.8p20);
+}
 template <>
 __device__ __forceinline__ uint32_t from_torus_fast<uint32_t>(double t) {
   const double fr = t - rint(t);
   return (uint32_t)__double2loint(fr + 0x1.8p20);
+}
+
+// Decomposition state in 32 bits. Only the top BL*L bits of the word (plus the rounding bit
+// below them) enter the digits; when those lie in the high dword the 64-bit shifts of the
+// generic form are not needed. The result equals decomp_init_state() for every input.
+template <typename T, int BL, int L>
+__device__ __forceinline__ uint32_t digit_state32(T x) {
+  constexpr int BITS = Torus<T>::BITS;
+  constexpr int NON_REP = BITS - BL * L;
+  static_assert(BL * L <= 31, "decomposition wider than 31 bits");
+  if constexpr (BITS == 64 && NON_REP >= 33) {
+    const uint32_t hi = (uint32_t)(x >> 32);
+    // (hi >> s) + rounding bit == (hi + 2^(s-1)) >> s up to a carry out of bit 31, which the
+    // mask would drop anyway
+    constexpr int S = NON_REP - 32;
+    return ((hi + (1u << (S - 1))) >> S) & ((1u << (BL * L)) - 1u);
+  } else {
+    return (uint32_t)decomp_init_state<T>(x, BL, L);
+  }
+}
+// next signed digit (level L first); same recurrence as decompose_one_level, in 32 bits
+template <int BL, int L>
+__device__ __forceinline__ int32_t digit_next32(uint32_t& state) {
+  if constexpr (L == 1) {
+    // single level: state already holds BL bits; carry = (res > B/2)
+    const uint32_t res = state;
+    return (int32_t)res - ((res > (1u << (BL - 1))) ? (1 << BL) : 0);
+  } else {
+    return (int32_t)decomp_next<uint32_t>(state, BL);
+  }
 }
 
 // broadcast lane 0's value through SGPRs so that the compiler sees a wave-uniform value
@@ -285,22 +338,22 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
       const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
       // gather rotated - own, start the decomposition
       const T* p = ct0 + r * N;
-      T st0[8], st1[8];
+      uint32_t st0[8], st1[8];
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
         const T x0 = rotated_coeff<T>(p, j0, a_hat, N) - p[j0];
         const T x1 = rotated_coeff<T>(p, j1, a_hat, N) - p[j1];
-        st0[q] = decomp_init_state<T>(x0, BL, L);
-        st1[q] = decomp_init_state<T>(x1, BL, L);
+        st0[q] = digit_state32<T, BL, L>(x0);
+        st1[q] = digit_state32<T, BL, L>(x1);
       }
 #pragma unroll
       for (int l = L; l >= 1; l--) {
         double2 x[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-          const S g0 = decomp_next<T>(st0[q], BL), g1 = decomp_next<T>(st1[q], BL);
-          x[q] = cmul(make_double2((double)(int32_t)g0, (double)(int32_t)g1), tab[TAB_TWIST + 64 * q + lane]);
+          const int32_t g0 = digit_next32<BL, L>(st0[q]), g1 = digit_next32<BL, L>(st1[q]);
+          x[q] = cmul(make_double2((double)g0, (double)g1), tab[TAB_TWIST + 64 * q + lane]);
         }
         fft512_forward(x, lane, tab, sre, sim);
 #pragma unroll
@@ -343,8 +396,8 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
         for (int q = 0; q < 8; q++) {
           const uint32_t j0 = 64 * q + lane;
           const double2 v = cmul_conj(z[q], tab[TAB_TWIST + j0]);
-          pc[j0] += from_torus_fast<T>(v.x);
-          pc[j0 + M] += from_torus_fast<T>(v.y);
+          pc[j0] = torus_accumulate(pc[j0], v.x);
+          pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
         }
       }
     }
