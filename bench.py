@@ -127,22 +127,14 @@ def main() -> None:
         dk = DeviceServerKey.from_standard_keys(ctx, p, bsk, ksk, variant=args.variant)
     key_broadcast_ms = None
     if world > 1:
-        meta = torch.zeros(2, dtype=torch.int64, device=device)
-        if rank == 0:
-            meta[0], meta[1] = dk.blob_size(), dk.variant
-        dist.broadcast(meta, 0)
-        blob = torch.empty(int(meta[0].item()), dtype=torch.uint8, device=device)
-        if rank == 0:
-            dk.export_blob(blob, torch.cuda.current_stream().cuda_stream)
+        from concrete_amd.distributed import replicate_server_key
+
         torch.cuda.synchronize()
         dist.barrier()
         tb = time.perf_counter()
-        dist.broadcast(blob, 0)
+        dk = replicate_server_key(ctx, p, dk if rank == 0 else None)
         torch.cuda.synchronize()
         key_broadcast_ms = (time.perf_counter() - tb) * 1e3
-        if rank != 0:
-            dk = DeviceServerKey.from_device_blob(ctx, p, blob, int(meta[1].item()))
-        del blob
     key_setup_s = time.perf_counter() - t_key
 
     lut = CL.shortint_accumulator(p, lambda x: x % p.message_modulus)

@@ -89,6 +89,25 @@ SYMBOLS.update({
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One process, one HIP runtime. PyTorch-ROCm ships its own libamdhip64; if this library were
+    loaded first it would bind to the system copy and torch would later bring a second, mismatched
+    runtime (its device enumeration then fails). Loading torch's copy first makes both share it.
+    A caller that never uses torch (a C or Rust host) simply gets the system runtime."""
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for name in ("libamdhip64.so",):
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib() -> C.CDLL:
     """Load the shared library (once). Raises if it has not been built."""
     global _lib
@@ -97,6 +116,7 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "to compile the HIP kernels for gfx950. There is no CPU fallback.")
+        _preload_torch_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)

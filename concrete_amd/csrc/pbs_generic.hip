@@ -184,15 +184,20 @@ unsigned generic_threads(uint32_t N) {
 
 size_t generic_tables_count(uint32_t N) { return (size_t)(N / 2) + (size_t)(N / 4 ? N / 4 : 1); }
 
+// cos and sin go through volatile pointers so that the compiler cannot merge the pair into one
+// sincos() call: the table then holds the same libm results as the CPU restatement's.
+static double (*volatile libm_cos)(double) = ::cos;
+static double (*volatile libm_sin)(double) = ::sin;
+
 void generic_fill_tables(uint32_t N, double2* t) {
   const uint32_t M = N / 2;
   for (uint32_t j = 0; j < M; j++) {
     const double ang = M_PI * (double)j / (double)N;
-    t[j] = make_double2(std::cos(ang), std::sin(ang));
+    t[j] = make_double2(libm_cos(ang), libm_sin(ang));
   }
   for (uint32_t j = 0; j < M / 2; j++) {
     const double ang = -2.0 * M_PI * (double)j / (double)M;
-    t[M + j] = make_double2(std::cos(ang), std::sin(ang));
+    t[M + j] = make_double2(libm_cos(ang), libm_sin(ang));
   }
 }
 

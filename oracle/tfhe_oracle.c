@@ -116,6 +116,12 @@ void orc_boolean_accumulator_u32(const orc_params* p, uint32_t* glwe_out) {
 }
 
 /* -------------------------------------------------------------------- fft -- */
+/* cos and sin are called through volatile pointers so that no compiler merges the pair into a
+ * sincos() call: the twiddle values are then the same libm results in every build of this file
+ * and of the GPU library, which is part of the bit-for-bit contract stated at the top. */
+static double (*volatile orc_cos)(double) = cos;
+static double (*volatile orc_sin)(double) = sin;
+
 struct orc_fft_plan {
   uint32_t N, M, logM;
   double *tw_re, *tw_im; /* twist e^{i pi j / N}, j < M */
@@ -134,8 +140,8 @@ orc_fft_plan* orc_fft_plan_create(uint32_t N) {
   pl->tw_im = (double*)aligned_alloc(64, sizeof(double) * M);
   for (uint32_t j = 0; j < M; j++) {
     const double a = M_PI * (double)j / (double)N;
-    pl->tw_re[j] = cos(a);
-    pl->tw_im[j] = sin(a);
+    pl->tw_re[j] = orc_cos(a);
+    pl->tw_im[j] = orc_sin(a);
   }
   const size_t st = (M > 1) ? M : 1;
   pl->st_re = (double*)aligned_alloc(64, sizeof(double) * ((st + 7) / 8 * 8));
@@ -145,8 +151,8 @@ orc_fft_plan* orc_fft_plan_create(uint32_t N) {
     const uint32_t half = len / 2;
     for (uint32_t j = 0; j < half; j++) {
       const double a = -2.0 * M_PI * (double)j / (double)len;
-      pl->st_re[off + j] = cos(a);
-      pl->st_im[off + j] = sin(a);
+      pl->st_re[off + j] = orc_cos(a);
+      pl->st_im[off + j] = orc_sin(a);
     }
     off += half;
   }

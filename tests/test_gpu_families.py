@@ -1,0 +1,179 @@
+"""GPU parity across parameter families and edge cases, through the C ABI.
+
+The workgroup-per-ciphertext kernel covers every parameter set and performs the oracle's exact
+sequence of IEEE-754 operations, so outputs are compared bit for bit. The LWE dimension is
+shortened (n = 6..24 CMUX iterations instead of 567..991): the kernels are the same, the loop is
+shorter, and the oracle finishes in seconds.
+"""
+import dataclasses
+
+import numpy as np
+import pytest
+
+import concrete_amd.parameters as P
+from concrete_amd.backend import CAMD_PBS_AUTO, CAMD_PBS_GENERIC, CAMD_PBS_WAVE, DeviceServerKey
+from oracle import cpu_oracle as O
+from conftest import get_keys
+
+pytestmark = pytest.mark.gpu
+
+
+def device_key(ctx, ks, variant=CAMD_PBS_GENERIC):
+    return DeviceServerKey.from_standard_keys(ctx, ks.device_params(), ks.bsk, ks.ksk, variant=variant, torus_bits=ks.bits)
+
+
+SHORTINT_FAMILIES = [
+    ("PARAM_MESSAGE_1_CARRY_1", 8),    # N=256,  k=6
+    ("PARAM_MESSAGE_1_CARRY_2", 8),    # N=512,  k=3
+    ("PARAM_MESSAGE_2_CARRY_2", 12),   # N=1024, k=2
+    ("PARAM_MESSAGE_2_CARRY_3", 8),    # N=2048, k=1
+    ("PARAM_MESSAGE_2_CARRY_4", 6),    # N=4096, k=1, two levels
+    ("PARAM_MESSAGE_3_CARRY_4", 6),    # N=8192, k=1, two levels
+    ("PARAM_MESSAGE_4_CARRY_4", 6),    # N=16384, k=1, two levels (the largest-polynomial class)
+    ("PARAM_MESSAGE_1_CARRY_7", 6),    # N=16384, three levels
+]
+
+
+@pytest.mark.parametrize("pname,n", SHORTINT_FAMILIES)
+def test_ks_pbs_bit_exact_every_family(gpu_ctx, pname, n):
+    p = P.SHORTINT_BY_NAME[pname]
+    ks = get_keys(p, 64, n_override=n)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks)
+    msg, sup = p.message_modulus, p.message_modulus * p.carry_modulus
+    fs = [lambda x: x % msg, lambda x: x // msg]
+    luts = [o.generate_accumulator(f) for f in fs]
+    for l in luts:
+        dk.upload_lut(l)
+    delta = O.shortint_delta(p)
+    count = 5
+    msgs = [(3 * i + 1) % sup for i in range(count)]
+    cts = np.stack([o.lwe_encrypt(ks.rng, ks.glwe, m * delta, ks.lwe_std) for m in msgs])
+    ids = (np.arange(count) % 2).astype(np.uint32)
+    got = dk.ks_pbs(cts, ids)
+    want = o.ks_pbs_batch(ks.ksk, ks.fbsk, np.concatenate(luts), ids, cts, threads=4)
+    assert np.array_equal(got, want)
+    # standalone entry points agree with the fused call
+    small = dk.ks(cts)
+    assert np.array_equal(small, np.stack([o.keyswitch(ks.ksk, c) for c in cts]))
+    assert np.array_equal(dk.pbs(small, ids), want)
+    dk.close()
+
+
+@pytest.mark.parametrize("params", [P.DEFAULT_PARAMETERS, P.TFHE_LIB_PARAMETERS])
+def test_boolean_pbs_ks_bit_exact(gpu_ctx, params):
+    """32-bit torus, bootstrap then keyswitch (concrete-boolean cpu.rs:215-259)."""
+    ks = get_keys(params, 32, n_override=16)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks)
+    acc = o.boolean_accumulator()
+    dk.upload_lut(acc)
+    T, F = 1 << 29, 7 << 29
+    rows = []
+    for a in (False, True):
+        for b in (False, True):
+            ca = o.lwe_encrypt(ks.rng, ks.small, T if a else F, params.lwe_modular_std_dev)
+            cb = o.lwe_encrypt(ks.rng, ks.small, T if b else F, params.lwe_modular_std_dev)
+            buf = (np.uint32(0) - (ca + cb)).astype(np.uint32)
+            buf[-1] += np.uint32(T)
+            rows.append(buf)
+    cts = np.stack(rows)
+    got = dk.pbs_ks(cts)
+    want = o.pbs_ks_batch(ks.ksk, ks.fbsk, acc, None, cts, threads=2)
+    assert got.dtype == np.uint32 and np.array_equal(got, want)
+    big = dk.pbs(cts)
+    assert np.array_equal(big, np.stack([o.bootstrap(ks.fbsk, acc, c) for c in cts]))
+    assert np.array_equal(dk.ks(big), want)
+    dk.close()
+
+
+def test_full_size_boolean_nand_truth_table(gpu_ctx):
+    """BASELINE configs[0] on the GPU: NAND at DEFAULT_PARAMETERS with the full n = 586."""
+    p = P.DEFAULT_PARAMETERS
+    ks = get_keys(p, 32)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_AUTO)
+    acc = o.boolean_accumulator()
+    dk.upload_lut(acc)
+    T, F = 1 << 29, 7 << 29
+    rows, want_bits = [], []
+    for rep in range(4):
+        for a in (False, True):
+            for b in (False, True):
+                ca = o.lwe_encrypt(ks.rng, ks.small, T if a else F, p.lwe_modular_std_dev)
+                cb = o.lwe_encrypt(ks.rng, ks.small, T if b else F, p.lwe_modular_std_dev)
+                buf = (np.uint32(0) - (ca + cb)).astype(np.uint32)
+                buf[-1] += np.uint32(T)
+                rows.append(buf)
+                want_bits.append(not (a and b))
+    cts = np.stack(rows)
+    got = dk.pbs_ks(cts)
+    want = o.pbs_ks_batch(ks.ksk, ks.fbsk, acc, None, cts, threads=8)
+    if dk.variant == CAMD_PBS_GENERIC:
+        assert np.array_equal(got, want)
+    for i, bit in enumerate(want_bits):
+        assert (o.lwe_phase(ks.small, got[i]) < (1 << 31)) == bit
+        assert (o.lwe_phase(ks.small, want[i]) < (1 << 31)) == bit
+    dk.close()
+
+
+@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC, CAMD_PBS_WAVE])
+def test_edge_cases_2_2(gpu_ctx, variant):
+    """Empty batch, ragged batch sizes, aliasing of input and output, trivial inputs, lut ids."""
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    ks = get_keys(p, 64, n_override=10)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks, variant)
+    luts = [o.generate_accumulator(f) for f in (lambda x: x % 4, lambda x: x // 4, lambda x: 15 - x)]
+    for l in luts:
+        dk.upload_lut(l)
+    assert dk.lut_count == 3
+    # empty
+    assert dk.ks_pbs(np.zeros((0, o.big + 1), dtype=np.uint64)).shape == (0, o.big + 1)
+    delta = O.shortint_delta(p)
+    for count in (1, 3, 4, 5, 9, 17):
+        msgs = [(5 * i + 2) % 16 for i in range(count)]
+        cts = np.stack([o.lwe_encrypt(ks.rng, ks.glwe, m * delta, ks.lwe_std) for m in msgs])
+        cts[0, :-1] = 0  # one trivial ciphertext in every batch
+        ids = (np.arange(count) % 3).astype(np.uint32)
+        got = dk.ks_pbs(cts, ids)
+        want = o.ks_pbs_batch(ks.ksk, ks.fbsk, np.concatenate(luts), ids, cts, threads=4)
+        if variant == CAMD_PBS_GENERIC:
+            assert np.array_equal(got, want)
+        assert np.array_equal(got[0], want[0])  # trivial input: exact in every family
+        for i in range(count):
+            assert O.shortint_decode(p, o.lwe_phase(ks.glwe, got[i])) == O.shortint_decode(p, o.lwe_phase(ks.glwe, want[i]))
+    # lut id out of range is an error on the host path
+    with pytest.raises(Exception):
+        dk.ks_pbs(cts, np.full(cts.shape[0], 7, dtype=np.uint32))
+    dk.close()
+
+
+def test_device_pointer_entry_points(gpu_ctx):
+    """Device-resident inputs (torch owns the memory), in-place output, explicit stream."""
+    import torch
+
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    ks = get_keys(p, 64, n_override=10)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_GENERIC)
+    lut = o.generate_accumulator(lambda x: x % 4)
+    dk.upload_lut(lut)
+    delta = O.shortint_delta(p)
+    cts = np.stack([o.lwe_encrypt(ks.rng, ks.glwe, m * delta, ks.lwe_std) for m in range(16)])
+    want = o.ks_pbs_batch(ks.ksk, ks.fbsk, lut, None, cts, threads=4)
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        dk.ks_pbs_device(d_in, None, d_in, 16, stream.cuda_stream)  # output aliases input
+    stream.synchronize()
+    assert np.array_equal(d_in.cpu().numpy().view(np.uint64), want)
+    # blob export / import gives an equal key
+    blob = torch.empty(dk.blob_size(), dtype=torch.uint8, device="cuda")
+    dk.export_blob(blob)
+    torch.cuda.synchronize()
+    dk2 = DeviceServerKey.from_device_blob(gpu_ctx, ks.device_params(), blob, dk.variant)
+    dk2.upload_lut(lut)
+    assert np.array_equal(dk2.ks_pbs(cts), want)
+    dk.close()
+    dk2.close()

@@ -1,0 +1,179 @@
+"""CPU tests of the host side: the C ABI library loads and exports every declared symbol, the
+client-side operations agree bit for bit with the oracle, the shortint mirror encodes and decodes
+like the reference, and the multi-process sharding/broadcast plumbing works under gloo."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import concrete_amd.parameters as P
+from concrete_amd import _ffi, client as CL
+from concrete_amd.distributed import shard_bounds
+from oracle import cpu_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in os.listdir(os.path.join(ROOT, "include")):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(camd_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _ffi.lib()
+    declared = declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/ but not exported"
+    # and the Python binding table covers the headers
+    assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
+    assert b"gfx950" in lib.camd_version()
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    """Without a usable device the library reports CAMD_ENODEV (or the device is there)."""
+    lib = _ffi.lib()
+    h = C.c_void_p()
+    rc = lib.camd_context_create(0, C.byref(h))
+    if rc != 0:
+        assert rc in (-4, -2, -1)
+        assert len(lib.camd_last_error()) > 0
+        with pytest.raises(_ffi.CamdError):
+            _ffi.check(rc)
+    else:
+        lib.camd_context_destroy(h)
+
+
+def test_bad_arguments_are_rejected():
+    lib = _ffi.lib()
+    assert lib.camd_context_create(0, None) == -1
+    assert lib.camd_lut_upload(None, None, None) == -1
+    assert lib.camd_ks_pbs_batch(None, None, None, None, 4) == -1
+    assert lib.camd_ks_pbs_batch(None, None, None, None, 0) == -1
+    rng = CL.Rng(1)
+    with pytest.raises(_ffi.CamdError):
+        _ffi.check(lib.camd_client_gen_binary_key(C.byref(rng.state), 48, 8, None))
+
+
+@pytest.mark.parametrize("bits,params", [(64, P.PARAM_MESSAGE_2_CARRY_2), (64, P.PARAM_MESSAGE_1_CARRY_1),
+                                         (32, P.DEFAULT_PARAMETERS)])
+def test_client_ops_equal_oracle(bits, params):
+    o = O.Oracle(params, bits)
+    r1, r2 = O.Rng(77), CL.Rng(77)
+    n = 6
+    s1, s2 = o.gen_binary_key(r1, n), CL.gen_binary_key(r2, bits, n)
+    big = params.glwe_dimension * params.polynomial_size
+    g1, g2 = o.gen_binary_key(r1, big), CL.gen_binary_key(r2, bits, big)
+    assert np.array_equal(s1, s2) and np.array_equal(g1, g2)
+    assert np.array_equal(o.gen_bsk(r1, s1, g1), CL.gen_bootstrap_key(r2, params, bits, s2, g2, threads=3))
+    assert np.array_equal(o.gen_ksk(r1, g1, s1), CL.gen_keyswitch_key(r2, params, bits, g2, s2))
+    pt = 5 << (bits - 5)
+    c1 = o.lwe_encrypt(r1, g1, pt, params.lwe_modular_std_dev)
+    c2 = CL.lwe_encrypt(r2, bits, g2, [pt], params.lwe_modular_std_dev)[0]
+    assert np.array_equal(c1, c2)
+    assert o.lwe_phase(g1, c1) == int(CL.lwe_phase(bits, g2, c2)[0])
+
+
+def test_accumulators_equal_oracle():
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    o = O.Oracle(p, 64)
+    for f in (lambda x: x % 4, lambda x: x // 4, lambda x: (x * 3) % 16):
+        assert np.array_equal(o.generate_accumulator(f), CL.shortint_accumulator(p, f))
+    b = P.DEFAULT_PARAMETERS
+    assert np.array_equal(O.Oracle(b, 32).boolean_accumulator(), CL.boolean_accumulator(b))
+
+
+def test_shortint_client_key_roundtrip():
+    """encrypt / decrypt of engine/client_side.rs:45-143, every message and carry value."""
+    from concrete_amd.shortint import ClientKey
+
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    cks = ClientKey.new(p, seed=3)
+    for m in range(16):
+        ct = cks.unchecked_encrypt(m)
+        assert ct.degree == 15 and ct.ct.shape == (2049,)
+        assert cks.decrypt_message_and_carry(ct) == m
+        assert cks.decrypt(ct) == m % 4
+    ct = cks.encrypt(7)
+    assert ct.degree == 3 and cks.decrypt(ct) == 3
+    ct = cks.encrypt_with_message_modulus(5, 8)
+    assert (ct.message_modulus, ct.carry_modulus, ct.degree) == (8, 2, 7)
+    assert cks.decrypt_message_and_carry(ct) == 5
+    # decode rounding: half a box below and above
+    delta = (1 << 63) // 16
+    assert cks.decode(3 * delta + delta // 2 - 1) == 3 and cks.decode(3 * delta + delta // 2) == 4
+    assert cks.decode((1 << 64) - 1) == 0 or cks.decode((1 << 64) - 1) == 32
+
+
+def test_shard_bounds_partition():
+    for total in (0, 1, 7, 16384, 131072, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from concrete_amd.distributed import shard_bounds, broadcast_blob
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+# rank 0 owns the key blob; everyone ends up with the same bytes
+meta = torch.zeros(2, dtype=torch.int64)
+blob = None
+if rank == 0:
+    g = torch.Generator().manual_seed(5)
+    blob = torch.randint(0, 256, (123457,), dtype=torch.uint8, generator=g)
+    meta[0], meta[1] = blob.numel(), 2
+blob, meta = broadcast_blob(blob, meta, 0)
+g = torch.Generator().manual_seed(5)
+want = torch.randint(0, 256, (123457,), dtype=torch.uint8, generator=g)
+assert torch.equal(blob, want) and int(meta[1]) == 2
+# index sharding of a batch: every rank transforms its own shard, the union is the whole batch
+total = 1001
+batch = torch.arange(total, dtype=torch.int64)
+b, e = shard_bounds(total, world, rank)
+mine = batch[b:e] * 3 + 1          # stands in for the per-ciphertext work, no communication
+counts = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
+gathered = [torch.empty(c, dtype=torch.int64) for c in counts]
+dist.all_gather(gathered, mine) if len(set(counts)) == 1 else None
+if len(set(counts)) != 1:
+    # ragged shards: gather through padded tensors
+    pad = max(counts)
+    padded = torch.zeros(pad, dtype=torch.int64); padded[: e - b] = mine
+    outs = [torch.zeros(pad, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(outs, padded)
+    gathered = [o[:c] for o, c in zip(outs, counts)]
+assert torch.equal(torch.cat(gathered), batch * 3 + 1)
+# max-over-ranks timing reduction used by the benchmark
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t) == float(world)
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_two_process_gloo_plumbing(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", str(script), ROOT]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("ok") == 2

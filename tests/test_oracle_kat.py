@@ -1,0 +1,253 @@
+"""CPU tests of the oracle: known-answer and algebraic tests that pin the CPU restatement.
+
+The reference holds no golden vectors for this path (its tests are randomized decrypt-equality
+checks), so the oracle is pinned by (1) the integer specifications that are in the reference tree,
+checked here against independent pure-Python restatements and committed fixtures, (2) identities
+that hold for any correct implementation (decomposer reconstruction, FFT product == schoolbook
+product, bootstrap of a trivial ciphertext == table look-up, noise-free round trips) and (3) the
+reference's own decrypt-level test properties (tests.rs:219-368 of concrete-shortint).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import concrete_amd.parameters as P
+from oracle import cpu_oracle as O
+from conftest import get_keys
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+M64 = (1 << 64) - 1
+
+
+# ---------------------------------------------------------------- accumulator (engine/mod.rs:130-178)
+def py_accumulator(p, f):
+    """Independent restatement of generate_accumulator_with_engine in plain Python."""
+    sup = p.message_modulus * p.carry_modulus
+    N, k = p.polynomial_size, p.glwe_dimension
+    box = N // sup
+    delta = (1 << 63) // sup
+    acc = [0] * N
+    for i in range(sup):
+        for j in range(box):
+            acc[i * box + j] = (f(i) * delta) & M64
+    half = box // 2
+    for j in range(half):
+        acc[j] = (-acc[j]) & M64
+    acc = acc[half:] + acc[:half]
+    return np.array([0] * (k * N) + acc, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("pname", ["PARAM_MESSAGE_2_CARRY_2", "PARAM_MESSAGE_1_CARRY_1", "PARAM_MESSAGE_4_CARRY_4",
+                                   "PARAM_MESSAGE_3_CARRY_3"])
+def test_accumulator_matches_spec(pname):
+    p = P.SHORTINT_BY_NAME[pname]
+    o = O.Oracle(p, 64)
+    msg = p.message_modulus
+    for f in (lambda x: x % msg, lambda x: x // msg, lambda x: (2 * x) % (msg * p.carry_modulus),
+              lambda x: ((x // msg) * (x % msg)) % msg):
+        assert np.array_equal(o.generate_accumulator(f), py_accumulator(p, f))
+
+
+def test_accumulator_golden():
+    """Committed fixture: first/last body words and a checksum per function at 2_2."""
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    o = O.Oracle(p, 64)
+    gold = json.load(open(os.path.join(GOLDEN, "accumulators_2_2.json")))
+    fs = {"id": lambda x: x, "mod4": lambda x: x % 4, "div4": lambda x: x // 4, "double": lambda x: (2 * x) % 16,
+          "mul_lsb": lambda x: ((x // 4) * (x % 4)) % 4}
+    for name, f in fs.items():
+        acc = o.generate_accumulator(f)
+        body = acc[p.glwe_dimension * p.polynomial_size:]
+        g = gold[name]
+        assert [int(v) for v in body[:4]] == g["first4"]
+        assert [int(v) for v in body[-4:]] == g["last4"]
+        assert int(np.bitwise_xor.reduce(body)) == g["xor"]
+        assert int(body.sum(dtype=np.uint64)) == g["sum"]
+
+
+def test_boolean_accumulator():
+    p = P.DEFAULT_PARAMETERS
+    acc = O.Oracle(p, 32).boolean_accumulator()
+    N, k = p.polynomial_size, p.glwe_dimension
+    assert (acc[: k * N] == 0).all() and (acc[k * N:] == (1 << 29)).all()  # cpu.rs:49-53, lib.rs:79
+
+
+# ---------------------------------------------------------------- modulus switch
+def test_modswitch_golden_and_spec():
+    gold = json.load(open(os.path.join(GOLDEN, "modswitch.json")))
+    for case in gold["cases"]:
+        x, log_n, bits = int(case["x"]), case["log2_n"], case["bits"]
+        out = x >> (bits - log_n - 2)
+        out += out & 1
+        out >>= 1
+        assert O.modswitch(x, log_n, bits) == out == case["out"]
+    # range: [0, 2N], both ends reached
+    assert O.modswitch(0, 10, 64) == 0 and O.modswitch(M64, 10, 64) == 2048
+    assert O.modswitch((1 << 32) - 1, 9, 32) == 1024
+
+
+# ---------------------------------------------------------------- signed decomposer
+DECOMP_SETS = [(23, 1, 64), (15, 2, 64), (11, 3, 64), (4, 3, 64), (3, 6, 64), (8, 2, 32), (2, 5, 32), (7, 3, 32)]
+
+
+@pytest.mark.parametrize("base_log,level,bits", DECOMP_SETS)
+def test_decomposer_identities(base_log, level, bits):
+    rs = np.random.RandomState(base_log * 100 + level)
+    mask = (1 << bits) - 1
+    half = 1 << (base_log - 1)
+    xs = [0, 1, mask, mask - 1, 1 << (bits - 1), (1 << (bits - 1)) - 1] + [int(v) for v in rs.randint(0, 2 ** 62, 200)]
+    non_rep = bits - base_log * level
+    for x in xs:
+        x &= mask
+        digits = O.decompose(x, base_log, level, bits)
+        closest = O.closest_representable(x, base_log, level, bits)
+        # digits are in [-B/2, B/2] and recompose to the closest representable value
+        assert all(-half <= d <= half for d in digits)
+        recomposed = sum(d << (bits - base_log * (l + 1)) for l, d in enumerate(digits)) & mask
+        assert recomposed == closest
+        # closest representable is within half a step of x (torus distance)
+        diff = (closest - x) & mask
+        diff = min(diff, (1 << bits) - diff)
+        assert diff <= (1 << (non_rep - 1))
+
+
+def test_decomposer_golden():
+    gold = json.load(open(os.path.join(GOLDEN, "decomposer.json")))
+    for case in gold["cases"]:
+        assert O.decompose(int(case["x"]), case["base_log"], case["level"], case["bits"]) == case["digits"]
+
+
+# ---------------------------------------------------------------- negacyclic FFT
+@pytest.mark.parametrize("N", [256, 1024, 4096])
+def test_fft_product_equals_schoolbook(N):
+    """forward(torus) x forward(integer digits) -> backward == exact negacyclic product."""
+    p = type("Q", (), dict(lwe_dimension=1, glwe_dimension=1, polynomial_size=N, pbs_base_log=23, pbs_level=1,
+                           ks_base_log=4, ks_level=3, lwe_modular_std_dev=0.0, glwe_modular_std_dev=0.0))()
+    o = O.Oracle(p, 64)
+    rs = np.random.RandomState(N)
+    a = rs.randint(0, 2 ** 63, N, dtype=np.uint64) * np.uint64(2) + rs.randint(0, 2, N).astype(np.uint64)
+    b = rs.randint(-(1 << 22), 1 << 22, N).astype(np.int64)
+    fa = o.fft_forward_torus(a)
+    fb = o.fft_forward_integer(b.astype(np.uint64))
+    M = N // 2
+    prod = np.concatenate([fa[:M] * fb[:M] - fa[M:] * fb[M:], fa[:M] * fb[M:] + fa[M:] * fb[:M]])
+    got = o.fft_add_backward_torus(prod, np.zeros(N, dtype=np.uint64))
+    want = O.negacyclic_schoolbook(a, b)
+    err = np.abs((got - want).view(np.int64).astype(np.float64)) / 2.0 ** 64
+    # products of 2^22-sized digits with torus values: f64 keeps about 2^-25 of the torus (worse as N grows)
+    assert err.max() < 2.0 ** -21
+
+
+def test_fft_roundtrip_exact_for_small_values():
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    o = O.Oracle(p, 64)
+    poly = (np.arange(1024, dtype=np.int64) - 512).astype(np.uint64)
+    f = o.fft_forward_integer(poly)
+    # backward "as torus" of integer values is 0 mod 1, up to the f64 rounding of the transform
+    back = o.fft_add_backward_torus(f, np.zeros(1024, dtype=np.uint64))
+    assert np.abs(back.view(np.int64).astype(np.float64)).max() / 2.0 ** 64 < 2.0 ** -36
+    back = o.fft_add_backward_torus(f * 2.0 ** -64, np.zeros(1024, dtype=np.uint64))
+    assert np.array_equal(back, poly)
+
+
+# ---------------------------------------------------------------- keyswitch / bootstrap algebra
+def test_keyswitch_of_trivial_is_trivial(keys_2_2):
+    ks = keys_2_2
+    ct = np.zeros(ks.o.big + 1, dtype=np.uint64)
+    ct[-1] = np.uint64(0x0123456789ABCDEF)
+    out = ks.o.keyswitch(ks.ksk, ct)
+    assert (out[:-1] == 0).all() and out[-1] == ct[-1]
+
+
+def test_keyswitch_preserves_phase(keys_2_2):
+    ks = keys_2_2
+    delta = O.shortint_delta(ks.params)
+    for m in range(16):
+        ct = ks.o.lwe_encrypt(ks.rng, ks.glwe, m * delta, ks.lwe_std)
+        small = ks.o.keyswitch(ks.ksk, ct)
+        e = (ks.o.lwe_phase(ks.small, small) - m * delta + 2 ** 63) % 2 ** 64 - 2 ** 63
+        assert abs(e) / 2.0 ** 64 < 2.0 ** -6  # well inside half a box for almost every sample
+
+
+def test_trivial_bootstrap_is_table_lookup():
+    """Mask = 0 skips every CMUX: out = sample_extract(lut * X^{-b_hat}); independent of the key."""
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    ks = get_keys(p, 64, n_override=4, noise=True)
+    o = ks.o
+    f = lambda x: (3 * x + 1) % 16
+    lut = o.generate_accumulator(f)
+    body = lut[p.glwe_dimension * p.polynomial_size:]
+    N = p.polynomial_size
+    for b in [0, 1 << 59, 5 << 59, (1 << 63) - 1, 1 << 63, M64, 0x0123456789ABCDEF]:
+        ct = np.zeros(ks.n + 1, dtype=np.uint64)
+        ct[-1] = np.uint64(b)
+        out = o.bootstrap(ks.fbsk, lut, ct)
+        bh = O.modswitch(b, 10, 64) % (2 * N)
+        want0 = int(body[bh]) if bh < N else (-int(body[bh - N])) & M64   # coefficient 0 of lut * X^{-bh}
+        assert int(out[-1]) == want0
+        assert (out[:-1] == 0).all()
+
+
+def test_noise_free_roundtrip_all_messages():
+    """With sigma = 0 keys: decrypt(KS+PBS(enc(m))) == f(m) for every m and several f."""
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    ks = get_keys(p, 64, n_override=24, noise=False)
+    o = ks.o
+    delta = O.shortint_delta(p)
+    fs = [lambda x: x, lambda x: x % 4, lambda x: x // 4, lambda x: (x * x) % 16]
+    luts = np.concatenate([o.generate_accumulator(f) for f in fs])
+    cts = np.stack([o.lwe_encrypt(ks.rng, ks.glwe, m * delta, 0.0) for m in range(16)] * len(fs))
+    ids = np.repeat(np.arange(len(fs)), 16).astype(np.uint32)
+    out = o.ks_pbs_batch(ks.ksk, ks.fbsk, luts, ids, cts, threads=4)
+    for i in range(len(cts)):
+        assert O.shortint_decode(p, o.lwe_phase(ks.glwe, out[i])) == fs[ids[i]](i % 16)
+
+
+def test_reference_properties_2_2(keys_2_2):
+    """concrete-shortint tests.rs:219-250 (keyswitch_bootstrap keeps the message) and :343-368
+    (accumulator for 2x), on the CPU oracle with real noise."""
+    ks = keys_2_2
+    p, o = ks.params, ks.o
+    delta = O.shortint_delta(p)
+    lut_id = o.generate_accumulator(lambda x: x % p.message_modulus)
+    lut_2x = o.generate_accumulator(lambda x: (2 * x) % p.message_modulus)
+    msgs = [0, 1, 2, 3, 3, 2, 1, 0]
+    cts = np.stack([o.lwe_encrypt(ks.rng, ks.glwe, m * delta, ks.lwe_std) for m in msgs])
+    a = o.ks_pbs_batch(ks.ksk, ks.fbsk, lut_id, None, cts, threads=4)
+    b = o.ks_pbs_batch(ks.ksk, ks.fbsk, lut_2x, None, cts, threads=4)
+    for i, m in enumerate(msgs):
+        assert O.shortint_decode(p, o.lwe_phase(ks.glwe, a[i])) % p.message_modulus == m
+        assert O.shortint_decode(p, o.lwe_phase(ks.glwe, b[i])) % p.message_modulus == (2 * m) % p.message_modulus
+
+
+def test_boolean_nand_reference_path():
+    """BASELINE configs[0]: one NAND at DEFAULT_PARAMETERS on the CPU path
+    (engine/mod.rs:364-405: -a - b + 1/8, then bootstrap, then keyswitch)."""
+    p = P.DEFAULT_PARAMETERS
+    ks = get_keys(p, 32)
+    o = ks.o
+    acc = o.boolean_accumulator()
+    T, F = 1 << 29, 7 << 29
+    for a in (False, True):
+        for b in (False, True):
+            ca = o.lwe_encrypt(ks.rng, ks.small, T if a else F, p.lwe_modular_std_dev)
+            cb = o.lwe_encrypt(ks.rng, ks.small, T if b else F, p.lwe_modular_std_dev)
+            buf = (np.uint32(0) - (ca + cb)).astype(np.uint32)
+            buf[-1] += np.uint32(T)
+            out = o.pbs_ks_batch(ks.ksk, ks.fbsk, acc, None, buf[None, :], threads=1)[0]
+            assert (o.lwe_phase(ks.small, out) < (1 << 31)) == (not (a and b))
+
+
+def test_tiny_transcript_golden():
+    """A noise-free n=4, N=256 KS+PBS transcript with fixed seed: inputs and outputs committed."""
+    g = np.load(os.path.join(GOLDEN, "tiny_transcript.npz"))
+    p = type("Q", (), dict(lwe_dimension=4, glwe_dimension=1, polynomial_size=256, pbs_base_log=15, pbs_level=2,
+                           ks_base_log=4, ks_level=3, message_modulus=2, carry_modulus=2,
+                           lwe_modular_std_dev=0.0, glwe_modular_std_dev=0.0))()
+    o = O.Oracle(p, 64)
+    fb = o.bsk_to_fourier(g["bsk"])
+    out = o.ks_pbs_batch(g["ksk"], fb, g["lut"], None, g["ct_in"], threads=1)
+    assert np.array_equal(out, g["ct_out"])
+    assert np.array_equal(np.stack([o.keyswitch(g["ksk"], c) for c in g["ct_in"]]), g["ct_ks"])
