@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libconcrete_amd.so")
+LIB_PATH = os.environ.get("CONCRETE_AMD_LIB") or os.path.join(_HERE, "_lib", "libconcrete_amd.so")
 
 CAMD_PBS_AUTO, CAMD_PBS_GENERIC, CAMD_PBS_WAVE = 0, 1, 2
 

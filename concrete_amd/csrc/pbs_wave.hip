@@ -21,8 +21,15 @@
 //   * Rows of the GGSW are consumed as soon as their transform is ready; the Fourier-domain
 //     sums for the k+1 output polynomials stay in registers.
 #include <cmath>
+#include <cstdlib>
 
 #include "kernels.hpp"
+
+// CAMD_ABLATE is a debug aid for timing experiments (results are wrong when it is set):
+//   1 = no lane exchanges, 2 = no key-row loads, 3 = no accumulator update, 4 = no rotation gather
+#ifndef CAMD_ABLATE
+#define CAMD_ABLATE 0
+#endif
 
 namespace camd {
 
@@ -86,6 +93,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
 #pragma unroll
   for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
   // exchange 1: register index b <-> lane bits 5:3
+#if CAMD_ABLATE != 1
 #pragma unroll
   for (int b = 0; b < 8; b++) {
     sre[b * ROW + lane] = x[b].x;
@@ -96,10 +104,12 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
     const int idx = hi * ROW + q * 8 + lo;
     x[q] = make_double2(sre[idx], sim[idx]);
   }
+#endif
   dft8<false>(x);
 #pragma unroll
   for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW1 + (b - 1) * 8 + lo]);
   // exchange 2: register index b' <-> lane bits 2:0 (XOR keeps both sides conflict-free)
+#if CAMD_ABLATE != 1
 #pragma unroll
   for (int b = 0; b < 8; b++) {
     const int idx = hi * ROW + b * 8 + (lo ^ b);
@@ -111,6 +121,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
     const int idx = hi * ROW + lo * 8 + (q ^ lo);
     x[q] = make_double2(sre[idx], sim[idx]);
   }
+#endif
   dft8<false>(x);
 }
 
@@ -119,6 +130,7 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
                                                double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
   dft8<true>(x);
+#if CAMD_ABLATE != 1
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + lo * 8 + (q ^ lo);
@@ -130,9 +142,11 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
     const int idx = hi * ROW + b * 8 + (lo ^ b);
     x[b] = make_double2(sre[idx], sim[idx]);
   }
+#endif
 #pragma unroll
   for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW1 + (b - 1) * 8 + lo]);
   dft8<true>(x);
+#if CAMD_ABLATE != 1
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + q * 8 + lo;
@@ -141,6 +155,7 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
   }
 #pragma unroll
   for (int b = 0; b < 8; b++) x[b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
+#endif
 #pragma unroll
   for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
   dft8<true>(x);
@@ -311,11 +326,21 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
   // does; their rows are never loaded.
   double2 bq[K + 1][8];
   auto load_rows = [&](uint32_t it, int r, int l) {
+#if CAMD_ABLATE == 5
+    const double2* brow = a.fbsk + ((((size_t)(it & 3) * L + (l - 1)) * (K + 1) + r) * (K + 1)) * M + lane;
+#else
     const double2* brow = a.fbsk + ((((size_t)it * L + (l - 1)) * (K + 1) + r) * (K + 1)) * M + lane;
+#endif
 #pragma unroll
     for (int c = 0; c <= K; c++)
 #pragma unroll
-      for (int g = 0; g < 8; g++) bq[c][g] = brow[(size_t)c * M + g * 64];
+      for (int g = 0; g < 8; g++) {
+#if CAMD_ABLATE == 2
+        bq[c][g] = make_double2(1e-3 * (double)(uintptr_t)brow, 2e-3);
+#else
+        bq[c][g] = brow[(size_t)c * M + g * 64];
+#endif
+      }
   };
   double2 acc[K + 1][8];
 #pragma unroll
@@ -342,8 +367,13 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+#if CAMD_ABLATE == 4
+        const T x0 = (T)(j0 * 0x9E3779B97F4A7C15ull + a_hat), x1 = (T)(j1 * 0xBF58476D1CE4E5B9ull + a_hat);
+        (void)p;
+#else
         const T x0 = rotated_coeff<T>(p, j0, a_hat, N) - p[j0];
         const T x1 = rotated_coeff<T>(p, j1, a_hat, N) - p[j1];
+#endif
         st0[q] = digit_state32<T, BL, L>(x0);
         st1[q] = digit_state32<T, BL, L>(x1);
       }
@@ -396,8 +426,12 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
         for (int q = 0; q < 8; q++) {
           const uint32_t j0 = 64 * q + lane;
           const double2 v = cmul_conj(z[q], tab[TAB_TWIST + j0]);
+#if CAMD_ABLATE == 3
+          asm volatile("" ::"v"(v.x), "v"(v.y));
+#else
           pc[j0] = torus_accumulate(pc[j0], v.x);
           pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
+#endif
         }
       }
     }
@@ -417,13 +451,319 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
   if (lane == 0) out[K * N] = ct0[K * N];
 }
 
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 as_double2(v4u v) {
+  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+
+// ---- interleaved transforms: S independent polynomials advance through the passes together ----
+// One wave, one exchange image: LDS operations of a wave execute in order, so the write/read
+// pair of stream s completes before the pair of stream s+1 touches the image, and while the
+// data of one stream is in flight the butterflies of the others keep the vector ALU busy.
+// Twiddle factors are read once per pass and reused by every stream.
+template <int S>
+__device__ __forceinline__ void fft512_forward_multi(double2 (&x)[S][8], int lane, const double2* tab, double* sre,
+                                                     double* sim) {
+  const int hi = lane >> 3, lo = lane & 7;
+  double2 w[7];
+#pragma unroll
+  for (int b = 1; b < 8; b++) w[b - 1] = tab[TAB_TW0 + (b - 1) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    dft8<false>(x[s]);
+#pragma unroll
+    for (int b = 1; b < 8; b++) x[s][b] = cmul(x[s][b], w[b - 1]);
+  }
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      sre[b * ROW + lane] = x[s][b].x;
+      sim[b * ROW + lane] = x[s][b].y;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int idx = hi * ROW + q * 8 + lo;
+      x[s][q] = make_double2(sre[idx], sim[idx]);
+    }
+  }
+#pragma unroll
+  for (int b = 1; b < 8; b++) w[b - 1] = tab[TAB_TW1 + (b - 1) * 8 + lo];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    dft8<false>(x[s]);
+#pragma unroll
+    for (int b = 1; b < 8; b++) x[s][b] = cmul(x[s][b], w[b - 1]);
+  }
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const int idx = hi * ROW + b * 8 + (lo ^ b);
+      sre[idx] = x[s][b].x;
+      sim[idx] = x[s][b].y;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int idx = hi * ROW + lo * 8 + (q ^ lo);
+      x[s][q] = make_double2(sre[idx], sim[idx]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; s++) dft8<false>(x[s]);
+}
+
+template <int S>
+__device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lane, const double2* tab, double* sre,
+                                                     double* sim) {
+  const int hi = lane >> 3, lo = lane & 7;
+  double2 w[7];
+#pragma unroll
+  for (int s = 0; s < S; s++) dft8<true>(x[s]);
+#pragma unroll
+  for (int b = 1; b < 8; b++) w[b - 1] = tab[TAB_TW1 + (b - 1) * 8 + lo];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int idx = hi * ROW + lo * 8 + (q ^ lo);
+      sre[idx] = x[s][q].x;
+      sim[idx] = x[s][q].y;
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const int idx = hi * ROW + b * 8 + (lo ^ b);
+      x[s][b] = make_double2(sre[idx], sim[idx]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int b = 1; b < 8; b++) x[s][b] = cmul_conj(x[s][b], w[b - 1]);
+    dft8<true>(x[s]);
+  }
+#pragma unroll
+  for (int b = 1; b < 8; b++) w[b - 1] = tab[TAB_TW0 + (b - 1) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int idx = hi * ROW + q * 8 + lo;
+      sre[idx] = x[s][q].x;
+      sim[idx] = x[s][q].y;
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++) x[s][b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
+  }
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int b = 1; b < 8; b++) x[s][b] = cmul_conj(x[s][b], w[b - 1]);
+    dft8<true>(x[s]);
+  }
+}
+
+// ---- the bootstrap, second schedule (single decomposition level) ----
+// Per CMUX: gather the k+1 rotated differences, run the k+1 forward transforms interleaved,
+// multiply-accumulate against the whole GGSW (held in registers, loaded during the previous
+// iteration's inverse transforms), run the k+1 inverse transforms interleaved, round and add.
+template <typename T, int K, int BL>
+__global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
+  constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = a.tables[t];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t ct = (size_t)blockIdx.x * WAVES + wave;
+  if (ct >= a.count) return;
+
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
+  T* ct0 = (T*)slab;
+  double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
+  double* sim = sre + PLANE;
+
+  const T* in = a.ct_in + ct * a.in_stride;
+  const uint32_t n = a.n;
+  const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
+  const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N);
+  {
+    const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+    const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+    for (int idx = lane; idx < R * N; idx += 64) {
+      const int c = idx >> LOGN, j = idx & (N - 1);
+      ct0[idx] = rotated_coeff<T>(lut + (size_t)c * N, j, d0, N);
+    }
+  }
+
+  // first iteration whose mask element is not zero (the reference skips the others)
+  uint32_t i = 0;
+  T a_cur = wave_uniform(in[0]);
+  while (i < n && a_cur == 0) {
+    i++;
+    a_cur = wave_uniform(in[i]);  // in[n] is the body: readable
+  }
+
+  // The GGSW of one iteration is R*R slabs of 8 registers (one 8 KiB slab per (row, col)).
+  // NA of them are parked in the accumulation registers (AGPRs): their loads are issued one
+  // iteration ahead and write the AGPRs directly, so they cost no vector registers while in
+  // flight across the inverse transforms, the rounding, the next gather and the next forward
+  // transforms. The remaining slabs do not fit the 256 AGPRs; they are loaded into vector
+  // registers at the top of their own iteration. The loads are inline assembly (the compiler
+  // cannot be told "load into an AGPR"), so the wait for them is explicit as well.
+  constexpr int NS = R * R;                     // slabs per iteration
+  constexpr int NA = NS * 32 <= 224 ? NS : 7;   // slabs that live in AGPRs
+  v4u bqa[NA][8];
+#pragma unroll
+  for (int sl = 0; sl < NA; sl++)
+#pragma unroll
+    for (int g = 0; g < 8; g++) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(bqa[sl][g].x));
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+
+  // The loop body runs once as a pure "load" pass (work = false) so that the key loads have a
+  // single site; afterwards every pass transforms iteration `cur` and loads iteration `i`.
+  bool work = false;
+  uint32_t a_hat = 0, cur = 0;
+  for (;;) {
+    double2 x[R][8];
+    v4u bqv[NS - NA > 0 ? NS - NA : 1][8];
+    if (work) {
+      // the slabs that do not fit the AGPRs: requested now, needed after the forward transforms
+#pragma unroll
+      for (int sl = NA; sl < NS; sl++) {
+        const char* base = (const char*)(a.fbsk + (size_t)cur * NS * M) + (size_t)sl * (M * sizeof(double2)) + 4096;
+#pragma unroll
+        for (int g = 0; g < 8; g++)
+          asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                       : "=v"(bqv[sl - NA][g])
+                       : "v"(lane_off), "s"(base), "n"(g * 1024 - 4096)
+                       : "memory");
+      }
+      // gather rotated - own, decompose (one level), twist
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const T* p = ct0 + r * N;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+          const T x0 = rotated_coeff<T>(p, j0, a_hat, N) - p[j0];
+          const T x1 = rotated_coeff<T>(p, j1, a_hat, N) - p[j1];
+          uint32_t s0 = digit_state32<T, BL, L>(x0), s1 = digit_state32<T, BL, L>(x1);
+          const int32_t g0 = digit_next32<BL, L>(s0), g1 = digit_next32<BL, L>(s1);
+          x[r][q] = cmul(make_double2((double)g0, (double)g1), tab[TAB_TWIST + j0]);
+        }
+      }
+      fft512_forward_multi<R>(x, lane, tab, sre, sim);
+      // acc[c] = sum_r GGSW[r][c] * F[r], written over x column by column is not possible
+      // (every column needs every row), so the sums go to a second array
+    }
+    double2 acc[R][8];
+    if (work) {
+      // every key load of this iteration must have landed before the products
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int sl = 0; sl < NA; sl++)
+        asm volatile("" : "+a"(bqa[sl][0]), "+a"(bqa[sl][1]), "+a"(bqa[sl][2]), "+a"(bqa[sl][3]),
+                          "+a"(bqa[sl][4]), "+a"(bqa[sl][5]), "+a"(bqa[sl][6]), "+a"(bqa[sl][7]));
+#pragma unroll
+      for (int sl = NA; sl < NS; sl++)
+        asm volatile("" : "+v"(bqv[sl - NA][0]), "+v"(bqv[sl - NA][1]), "+v"(bqv[sl - NA][2]), "+v"(bqv[sl - NA][3]),
+                          "+v"(bqv[sl - NA][4]), "+v"(bqv[sl - NA][5]), "+v"(bqv[sl - NA][6]), "+v"(bqv[sl - NA][7]));
+      auto key = [&](int r, int c, int g) -> double2 {
+        const int sl = r * R + c;
+        return as_double2(sl < NA ? bqa[sl < NA ? sl : 0][g] : bqv[sl >= NA ? sl - NA : 0][g]);
+      };
+#pragma unroll
+      for (int c = 0; c < R; c++)
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+          double2 v = cmul(key(0, c, g), x[0][g]);
+#pragma unroll
+          for (int r = 1; r < R; r++) v = cfma(key(r, c, g), x[r][g], v);
+          acc[c][g] = v;
+        }
+    }
+
+    // key rows of the next active iteration (index i), if any
+    const bool more = i < n;
+    if (more) {
+      const char* ggsw = (const char*)(a.fbsk + (size_t)i * NS * M);  // wave-uniform
+#pragma unroll
+      for (int sl = 0; sl < NA; sl++) {
+        // scalar base in the middle of the slab, eight 1 KiB pieces around it
+        const char* base = ggsw + (size_t)sl * (M * sizeof(double2)) + 4096;
+#pragma unroll
+        for (int g = 0; g < 8; g++)
+          asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                       : "=a"(bqa[sl][g])
+                       : "v"(lane_off), "s"(base), "n"(g * 1024 - 4096)
+                       : "memory");
+      }
+    }
+    const uint32_t next_i = i;
+    const uint32_t next_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
+    // scan ahead for the iteration after that one
+    if (more) {
+      i++;
+      a_cur = wave_uniform(in[i]);
+      while (i < n && a_cur == 0) {
+        i++;
+        a_cur = wave_uniform(in[i]);
+      }
+    }
+
+    if (work) {
+      fft512_inverse_multi<R>(acc, lane, tab, sre, sim);
+#pragma unroll
+      for (int c = 0; c < R; c++) {
+        T* pc = ct0 + c * N;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t j0 = 64 * q + lane;
+          const double2 v = cmul_conj(acc[c][q], tab[TAB_TWIST + j0]);
+          pc[j0] = torus_accumulate(pc[j0], v.x);
+          pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
+        }
+      }
+    }
+    if (!more) break;
+    work = true;
+    a_hat = next_hat;
+    cur = next_i;
+  }
+
+  T* out = a.ct_out + ct * a.out_stride;
+  for (int idx = lane; idx < K * N; idx += 64) {
+    const int c = idx >> LOGN, j = idx & (N - 1);
+    const T* p = ct0 + c * N;
+    out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
+  }
+  if (lane == 0) out[K * N] = ct0[K * N];
+}
+
 template <typename T, int K, int L, int BL>
 int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
   constexpr size_t lds = wave_lds_bytes<T, K>();
   static_assert(lds <= 160 * 1024, "LDS budget exceeded");
+  const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
+  static const int schedule = []() {
+    const char* e = getenv("CAMD_WAVE_SCHEDULE");
+    return e ? atoi(e) : 2;
+  }();
+  if constexpr (L == 1) {
+    if (schedule == 2) {
+      auto kern2 = wave_pbs_kernel_v2<T, K, BL>;
+      CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern2, dim3(grid), dim3(256), lds, stream, a);
+      CAMD_HIP(hipGetLastError());
+      return CAMD_OK;
+    }
+  }
   auto kern = wave_pbs_kernel<T, K, L, BL>;
   CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;
