@@ -514,11 +514,18 @@ __device__ __forceinline__ void fft512_forward_multi(double2 (&x)[S][8], int lan
   for (int s = 0; s < S; s++) dft8<false>(x[s]);
 }
 
-template <int S>
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// `hook(k)` is called at three points (k = 0, 1, 2), between the passes: the caller uses it to
+// slip independent memory requests into the stream.
+template <int S, typename Hook = NoHook>
 __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lane, const double2* tab, double* sre,
-                                                     double* sim) {
+                                                     double* sim, Hook hook = Hook()) {
   const int hi = lane >> 3, lo = lane & 7;
   double2 w[7];
+  hook(0);
 #pragma unroll
   for (int s = 0; s < S; s++) dft8<true>(x[s]);
 #pragma unroll
@@ -537,6 +544,7 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
       x[s][b] = make_double2(sre[idx], sim[idx]);
     }
   }
+  hook(1);
 #pragma unroll
   for (int s = 0; s < S; s++) {
 #pragma unroll
@@ -556,6 +564,7 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
 #pragma unroll
     for (int b = 0; b < 8; b++) x[s][b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
   }
+  hook(2);
 #pragma unroll
   for (int s = 0; s < S; s++) {
 #pragma unroll
@@ -627,7 +636,16 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   // single site; afterwards every pass transforms iteration `cur` and loads iteration `i`.
   bool work = false;
   uint32_t a_hat = 0, cur = 0;
+#ifdef CAMD_PROFILE
+  uint64_t tG = 0, tF = 0, tM = 0, tL = 0, tI = 0, tR = 0, t0, t1;
+#define STAMP(acc) t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1;
+#else
+#define STAMP(acc)
+#endif
   for (;;) {
+#ifdef CAMD_PROFILE
+    t0 = __builtin_amdgcn_s_memtime();
+#endif
     double2 x[R][8];
     v4u bqv[NS - NA > 0 ? NS - NA : 1][8];
     if (work) {
@@ -642,26 +660,58 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
                        : "v"(lane_off), "s"(base), "n"(g * 1024 - 4096)
                        : "memory");
       }
-      // gather rotated - own, decompose (one level), twist
+      // gather rotated - own, decompose (one level), twist. The LDS reads are issued in units
+      // of half a polynomial, one unit ahead of the arithmetic that consumes them, and the
+      // order is pinned so that the latency of a unit hides behind the previous unit's work.
+      T own0[2][4], own1[2][4], rot0[2][4], rot1[2][4];
+      auto issue = [&](int u) {
+        const T* p = ct0 + (u >> 1) * N;
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        const T* p = ct0 + r * N;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-          const T x0 = rotated_coeff<T>(p, j0, a_hat, N) - p[j0];
-          const T x1 = rotated_coeff<T>(p, j1, a_hat, N) - p[j1];
-          uint32_t s0 = digit_state32<T, BL, L>(x0), s1 = digit_state32<T, BL, L>(x1);
-          const int32_t g0 = digit_next32<BL, L>(s0), g1 = digit_next32<BL, L>(s1);
-          x[r][q] = cmul(make_double2((double)g0, (double)g1), tab[TAB_TWIST + j0]);
+        for (int t = 0; t < 4; t++) {
+          const uint32_t j0 = 64 * (4 * (u & 1) + t) + lane, j1 = j0 + M;
+          own0[u & 1][t] = p[j0];
+          own1[u & 1][t] = p[j1];
+          rot0[u & 1][t] = p[(j0 - a_hat) & (N - 1)];
+          rot1[u & 1][t] = p[(j1 - a_hat) & (N - 1)];
         }
+      };
+      auto consume = [&](int u) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int q = 4 * (u & 1) + t;
+          const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+          const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - rot0[u & 1][t]) : rot0[u & 1][t];
+          const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - rot1[u & 1][t]) : rot1[u & 1][t];
+          uint32_t s0 = digit_state32<T, BL, L>((T)(r0 - own0[u & 1][t]));
+          uint32_t s1 = digit_state32<T, BL, L>((T)(r1 - own1[u & 1][t]));
+          const int32_t g0 = digit_next32<BL, L>(s0), g1 = digit_next32<BL, L>(s1);
+          x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), tab[TAB_TWIST + j0]);
+        }
+      };
+      issue(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2 * R; u++) {
+        if (u + 1 < 2 * R) issue(u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(u);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      STAMP(tG)
       fft512_forward_multi<R>(x, lane, tab, sre, sim);
+      STAMP(tF)
       // acc[c] = sum_r GGSW[r][c] * F[r], written over x column by column is not possible
       // (every column needs every row), so the sums go to a second array
     }
     double2 acc[R][8];
-    if (work) {
+    if (!work) {
+      // load-only first pass: the inverse transforms and the rounding below run on zeros (they
+      // add nothing to the accumulator), which keeps a single site for the key loads
+#pragma unroll
+      for (int c = 0; c < R; c++)
+#pragma unroll
+        for (int g = 0; g < 8; g++) acc[c][g] = make_double2(0.0, 0.0);
+    } else {
       // every key load of this iteration must have landed before the products
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -687,13 +737,17 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
         }
     }
 
+    STAMP(tM)
     // key rows of the next active iteration (index i), if any
     const bool more = i < n;
-    if (more) {
-      const char* ggsw = (const char*)(a.fbsk + (size_t)i * NS * M);  // wave-uniform
-#pragma unroll
-      for (int sl = 0; sl < NA; sl++) {
-        // scalar base in the middle of the slab, eight 1 KiB pieces around it
+    // Key rows of the next active iteration (index i). Each slab is eight 1 KiB requests; they
+    // are spread over the inverse transforms and the rounding (one slab per slot) instead of
+    // being issued in one burst, so that the four waves of a CU do not queue 288 KiB on the
+    // load path at the same moment.
+    const char* ggsw = (const char*)(a.fbsk + (size_t)(more ? i : 0) * NS * M);  // wave-uniform
+    auto load_slab = [&](int sl) {
+      if (more) {
+        // scalar base in the middle of the slab, eight pieces around it
         const char* base = ggsw + (size_t)sl * (M * sizeof(double2)) + 4096;
 #pragma unroll
         for (int g = 0; g < 8; g++)
@@ -702,7 +756,12 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
                        : "v"(lane_off), "s"(base), "n"(g * 1024 - 4096)
                        : "memory");
       }
-    }
+    };
+    // slot k (0..5) takes slabs [SLOT_LO(k), SLOT_LO(k+1))
+    auto load_slot = [&](int k) {
+#pragma unroll
+      for (int sl = (k * NA) / 6; sl < ((k + 1) * NA) / 6; sl++) load_slab(sl);
+    };
     const uint32_t next_i = i;
     const uint32_t next_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
     // scan ahead for the iteration after that one
@@ -715,25 +774,50 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
       }
     }
 
-    if (work) {
-      fft512_inverse_multi<R>(acc, lane, tab, sre, sim);
+    STAMP(tL)
+    {
+      fft512_inverse_multi<R>(acc, lane, tab, sre, sim, load_slot);
+      STAMP(tI)
+      // untwist, round, add into the accumulator: old values are read one column ahead
+      T old0[2][8], old1[2][8];
+      auto issue_old = [&](int c) {
+        const T* pc = ct0 + c * N;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          old0[c & 1][q] = pc[64 * q + lane];
+          old1[c & 1][q] = pc[64 * q + lane + M];
+        }
+      };
+      issue_old(0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < R; c++) {
+        if (c + 1 < R) issue_old(c + 1);
+        if (c < 3) load_slot(3 + c);
+        __builtin_amdgcn_sched_barrier(0);
         T* pc = ct0 + c * N;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const uint32_t j0 = 64 * q + lane;
           const double2 v = cmul_conj(acc[c][q], tab[TAB_TWIST + j0]);
-          pc[j0] = torus_accumulate(pc[j0], v.x);
-          pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
+          pc[j0] = torus_accumulate(old0[c & 1][q], v.x);
+          pc[j0 + M] = torus_accumulate(old1[c & 1][q], v.y);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    STAMP(tR)
     if (!more) break;
     work = true;
     a_hat = next_hat;
     cur = next_i;
   }
+#ifdef CAMD_PROFILE
+  if ((ct == 0 || ct == 5000) && lane == 0)
+    printf("ct %lu cycles per iteration: gather %lu fwd %lu mac %lu load %lu inv %lu round %lu\n", (unsigned long)ct,
+           (unsigned long)(tG / n), (unsigned long)(tF / n), (unsigned long)(tM / n), (unsigned long)(tL / n),
+           (unsigned long)(tI / n), (unsigned long)(tR / n));
+#endif
 
   T* out = a.ct_out + ct * a.out_stride;
   for (int idx = lane; idx < K * N; idx += 64) {
