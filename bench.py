@@ -31,6 +31,20 @@ from concrete_amd.shortint import ClientKey  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector peak (the FP64 matrix peak is the same figure)
 SEED = 0xC0FFEE
+CPU_SAMPLE = 4096                # ciphertexts timed on the host cores (about 10 s on 16 threads)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "pmc_per_dispatch_wave_v2.json")
+
+
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes of this same
+    command (FETCH_SIZE and WRITE_SIZE cannot be read from inside the process). None when the
+    summary is absent."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            e = json.load(f)[kernel]
+        return float(e["hbm_fetch_bytes"] + e["hbm_write_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def flop_per_pbs(p) -> float:
@@ -212,7 +226,9 @@ def main() -> None:
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": measured_traffic("wave_pbs_kernel") if dk.variant == 2 and count == 1 << 14 else None,
+                "traffic_unit": "bytes per launch past the L2 (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                                "profiles/r1/pmc_per_dispatch_wave_v2.json); the Fourier key is 56.7 MB",
                 "kernel": "programmable bootstrap (blind rotation), f64 on the vector ALUs",
                 "flop_per_bootstrap": fpp,
                 "kernel_ms": tm["pbs_ms"],
@@ -229,7 +245,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
-            sample = cts[: 16 * cores].cpu().numpy().view(np.uint64)
+            sample = cts[: min(count, CPU_SAMPLE)].cpu().numpy().view(np.uint64)
             line["cpu_baseline"], cpu_out = cpu_baseline(p, bsk, ksk, lut, sample, cores)
             # parity on the sample: the GPU and the CPU restatement must decrypt identically
             dec_cpu = cks.decrypt_message_and_carry_batch(cpu_out)
