@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CONCRETE_AMD_LIB") or os.path.join(_HERE, "_lib", "libconcrete_amd.so")
 
-CAMD_PBS_AUTO, CAMD_PBS_GENERIC, CAMD_PBS_WAVE = 0, 1, 2
+CAMD_PBS_AUTO, CAMD_PBS_GENERIC, CAMD_PBS_WAVE, CAMD_PBS_BLOCK = 0, 1, 2, 3
 
 
 class CamdParams(C.Structure):

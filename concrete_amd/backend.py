@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import CAMD_PBS_AUTO, CAMD_PBS_GENERIC, CAMD_PBS_WAVE, check  # noqa: F401
+from ._ffi import CAMD_PBS_AUTO, CAMD_PBS_BLOCK, CAMD_PBS_GENERIC, CAMD_PBS_WAVE, check  # noqa: F401
 
 
 def _np_ptr(a: np.ndarray):

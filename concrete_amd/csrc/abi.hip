@@ -128,8 +128,13 @@ int pick_variant(const camd_params& p, int requested, int* out) {
     *out = CAMD_PBS_WAVE;
     return CAMD_OK;
   }
+  if (requested == CAMD_PBS_BLOCK) {
+    if (!block_supported(p)) return fail(CAMD_EINVAL, "the register-blocked kernel has no instance for this parameter set");
+    *out = CAMD_PBS_BLOCK;
+    return CAMD_OK;
+  }
   if (requested != CAMD_PBS_AUTO) return fail(CAMD_EINVAL, "unknown pbs_variant");
-  *out = wave_supported(p) ? CAMD_PBS_WAVE : CAMD_PBS_GENERIC;
+  *out = wave_supported(p) ? CAMD_PBS_WAVE : block_supported(p) ? CAMD_PBS_BLOCK : CAMD_PBS_GENERIC;
   return CAMD_OK;
 }
 
@@ -177,6 +182,8 @@ int key_fill(camd_server_key* key, const void* bsk_host, const void* ksk_host) {
   if (e != hipSuccess) rc = fail(CAMD_EHIP, std::string("bsk upload: ") + hipGetErrorString(e));
   if (rc == CAMD_OK) {
     if (key->variant == CAMD_PBS_WAVE) rc = wave_bsk_to_fourier<T>((const T*)d_std, (double2*)key->blob, key->tables, p, s);
+    else if (key->variant == CAMD_PBS_BLOCK)
+      rc = block_bsk_to_fourier<T>((const T*)d_std, (double2*)key->blob, key->tables, p.polynomial_size, polys, s);
     else rc = generic_bsk_to_fourier<T>((const T*)d_std, (double2*)key->blob, key->tables, p.polynomial_size, polys, s);
   }
   if (rc == CAMD_OK) {
@@ -213,6 +220,9 @@ int reserve_locked(camd_server_key* key, size_t count) {
     unsigned grid = 1;
     const size_t bytes = generic_scratch_bytes(p.glwe_dimension, p.polynomial_size, (int)key->word, &grid, count);
     rc = key->pbs_scratch.ensure(bytes);
+  } else if (key->variant == CAMD_PBS_BLOCK) {
+    unsigned grid = 1;
+    rc = key->pbs_scratch.ensure(block_scratch_bytes(p, &grid, count));
   }
   return rc;
 }
@@ -246,7 +256,13 @@ int run_pbs(camd_server_key* key, const T* in, size_t in_stride, const uint32_t*
   a.fbsk = key->fbsk(); a.tables = key->tables; a.scratch = key->pbs_scratch.ptr;
   a.n = p.lwe_dimension; a.k = p.glwe_dimension; a.N = p.polynomial_size; a.level = p.pbs_level; a.base_log = p.pbs_base_log;
   TimedRegion t(key, true, s);
-  return key->variant == CAMD_PBS_WAVE ? wave_launch_pbs<T>(a, s) : generic_launch_pbs<T>(a, s);
+  if (key->variant == CAMD_PBS_WAVE) return wave_launch_pbs<T>(a, s);
+  if (key->variant == CAMD_PBS_BLOCK) {
+    unsigned grid = 1;
+    block_scratch_bytes(p, &grid, count);
+    return block_launch_pbs<T>(a, grid, s);
+  }
+  return generic_launch_pbs<T>(a, s);
 }
 
 template <typename T>

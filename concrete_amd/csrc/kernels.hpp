@@ -18,7 +18,7 @@ struct PbsLaunch {
   size_t count;
   const double2* fbsk;       // Fourier bootstrap key in the layout of the kernel family
   const double2* tables;     // twiddle tables of the kernel family
-  void* scratch;             // per-workgroup scratch (generic family only)
+  void* scratch;             // per-workgroup scratch (generic and block families)
   uint32_t n, k, N, level, base_log;
 };
 
@@ -38,6 +38,16 @@ int generic_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* table
                            hipStream_t stream);
 template <typename T>
 int generic_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
+
+// ---- register-blocked workgroup-per-ciphertext bootstrap (pbs_block.hip) ----
+// uses the tables of the generic family; results are bit-identical to it
+bool block_supported(const camd_params& p);
+size_t block_scratch_bytes(const camd_params& p, unsigned* grid_out, size_t count);
+template <typename T>
+int block_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, uint32_t N, size_t polys,
+                         hipStream_t stream);
+template <typename T>
+int block_launch_pbs(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream);
 
 // ---- wave-per-polynomial bootstrap for N in {512, 1024, 2048} (pbs_wave.hip) ----
 bool wave_supported(const camd_params& p);

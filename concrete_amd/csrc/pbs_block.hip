@@ -1,0 +1,493 @@
+// Programmable bootstrap, register-blocked workgroup-per-ciphertext family.
+//
+// Replaces FftEngine::discard_bootstrap_lwe_ciphertext as the reference calls it at
+// concrete-shortint/src/engine/server_side/mod.rs:148-153 and
+// concrete-boolean/src/engine/bootstrapping/cpu.rs:231-236, for every polynomial size the
+// wave-per-ciphertext kernel has no instance for (N = 256 ... 16384, any level count).
+//
+// One workgroup of M/P threads (M = N/2 complex points, P = 8 points per thread; 4 or 2 for the
+// two smallest sizes) walks one ciphertext through all n CMUXes.
+//   * Transforms: each thread keeps P points in registers and runs log2(P) radix-2 stages on
+//     them between exchanges; an exchange goes through one LDS image of the polynomial with
+//     16-byte accesses and an XOR swizzle chosen per exchange so that both the store and the
+//     load side are free of bank conflicts. Stage twiddles of the first pass (the top log2(P)
+//     stages, whose tables are the large ones) come from global memory, all others from a
+//     compact per-stage copy in LDS.
+//   * The Fourier-domain sums of the external product stay in registers ((k+1) x P complex per
+//     thread): the multiply-accumulate against the key follows each forward transform directly
+//     and the inverse transforms start from registers.
+//   * The accumulator ((k+1) N torus words) lives in a per-workgroup global slab that stays in
+//     L2 / Infinity Cache; for multi-level decompositions the decomposer state left after the
+//     first level is parked there too (32 bits per coefficient), so the rotated accumulator is
+//     gathered once per row and CMUX.
+//   * Key layout: per polynomial [register r][thread t], i.e. exactly the order the forward
+//     transform leaves its outputs in; every key access is one coalesced 16-byte-per-lane load.
+//
+// Floating-point contract: the same as the radix-2 fallback kernel (pbs_generic.hip). A
+// radix-2 flow graph fixes, for every element, the sequence of IEEE-754 operations applied to
+// it; which thread executes a butterfly does not matter. Contraction is off, fused operations
+// are explicit fma(), twiddles are the host-computed tables of the fallback kernel, the
+// accumulation order over (level, row) and the rounding are the same. Output ciphertexts are
+// therefore bit-identical to the fallback kernel's and to the CPU restatement's.
+#pragma clang fp contract(off)
+#include "kernels.hpp"
+
+namespace camd {
+
+namespace {
+
+constexpr uint32_t SWZ_BITS = 4;  // a 16-lane group of ds_read_b128 must touch 16 distinct 16-byte units
+
+template <int PL>
+struct Blk {
+  static constexpr int P = 1 << PL;
+  // element held in register r of thread t while index bits [lo, lo+PL) are the in-register ones
+  static __device__ __forceinline__ uint32_t elem(uint32_t r, uint32_t t, uint32_t lo) {
+    return ((t >> lo) << (lo + PL)) | (r << lo) | (t & ((1u << lo) - 1u));
+  }
+  // LDS slot of element i for an exchange between passes whose smaller `lo` is key
+  static __device__ __forceinline__ uint32_t slot(uint32_t i, uint32_t key) {
+    if (key >= SWZ_BITS) return i;
+    return i ^ (((i >> (key + PL)) & ((1u << (SWZ_BITS - key)) - 1u)) << key);
+  }
+};
+
+// twiddle of stage bit b, butterfly index j (< 2^b): W_{2^(b+1)}^j
+__device__ __forceinline__ double2 stage_twiddle(bool from_global, const double2* __restrict__ gtw, const double2* ltw,
+                                                 uint32_t b, uint32_t j, uint32_t B) {
+  if (from_global) return gtw[(size_t)j << (B - 1u - b)];
+  return ltw[((1u << b) - 1u) + j];
+}
+
+// The arguments lo, top, B and from_global of the helpers below are compile-time constants at
+// every call site (the pass loops are fully unrolled), so all index arithmetic folds.
+
+// forward (decimation in frequency) stages lo+PL-1 ... lo, those above `top` already done
+template <int PL>
+__device__ __forceinline__ void forward_stages(double2 (&x)[1 << PL], uint32_t lo, uint32_t top, uint32_t B,
+                                               uint32_t t, bool from_global, const double2* __restrict__ gtw,
+                                               const double2* ltw) {
+  constexpr int P = 1 << PL;
+  const uint32_t tl = t & ((1u << lo) - 1u);
+#pragma unroll
+  for (int s = PL - 1; s >= 0; s--) {
+    const uint32_t b = lo + (uint32_t)s;
+    if (b > top) continue;
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+      if (r & (1 << s)) continue;
+      const uint32_t j = ((uint32_t)(r & ((1 << s) - 1)) << lo) | tl;
+      const double2 w = stage_twiddle(from_global, gtw, ltw, b, j, B);
+      const double2 a = x[r], c = x[r | (1 << s)];
+      x[r] = cadd(a, c);
+      x[r | (1 << s)] = cmul(csub(a, c), w);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keeps the twiddle loads of later stages from piling up in registers
+  }
+}
+
+// inverse (decimation in time, unnormalised) stages lo ... min(lo+PL-1, top)
+template <int PL>
+__device__ __forceinline__ void inverse_stages(double2 (&x)[1 << PL], uint32_t lo, uint32_t top, uint32_t B,
+                                               uint32_t t, bool from_global, const double2* __restrict__ gtw,
+                                               const double2* ltw) {
+  constexpr int P = 1 << PL;
+  const uint32_t tl = t & ((1u << lo) - 1u);
+#pragma unroll
+  for (int s = 0; s < PL; s++) {
+    const uint32_t b = lo + (uint32_t)s;
+    if (b > top) continue;
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+      if (r & (1 << s)) continue;
+      const uint32_t j = ((uint32_t)(r & ((1 << s) - 1)) << lo) | tl;
+      const double2 w = stage_twiddle(from_global, gtw, ltw, b, j, B);
+      const double2 a = x[r];
+      const double2 c = cmul_conj(x[r | (1 << s)], w);
+      x[r] = cadd(a, c);
+      x[r | (1 << s)] = csub(a, c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int PL>
+__device__ __forceinline__ void exchange(double2 (&x)[1 << PL], double2* buf, uint32_t t, uint32_t lo_from,
+                                         uint32_t lo_to) {
+  constexpr int P = 1 << PL;
+  const uint32_t key = lo_from < lo_to ? lo_from : lo_to;
+  __syncthreads();  // every load of the previous exchange has completed
+#pragma unroll
+  for (int r = 0; r < P; r++) buf[Blk<PL>::slot(Blk<PL>::elem(r, t, lo_from), key)] = x[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < P; r++) x[r] = buf[Blk<PL>::slot(Blk<PL>::elem(r, t, lo_to), key)];
+}
+
+// waves per SIMD an instance is compiled for: the Fourier sums ((k+1) P complex) and one polynomial
+// slice (P complex) stay in registers, plus about 40 registers of addresses and temporaries
+constexpr int block_waves(int PL, int KP1) {
+  const int need = KP1 * (1 << PL) * 4 + (1 << PL) * 4 + 40;
+  const int w = 512 / need;
+  if (PL >= 4) return 2;  // 512-thread workgroups, one per CU: nothing to gain from fewer registers
+  return w > 4 ? 4 : (w < 1 ? 1 : w);
+}
+
+constexpr int pass_lo(int B, int PL, int q) { return B - (q + 1) * PL > 0 ? B - (q + 1) * PL : 0; }
+
+// in: x[r] = element r*T + t (natural order). out: x[r] = position (t << PL) | r of the
+// bit-reversed spectrum. Pass q keeps index bits [lo_q, lo_q + PL) in registers.
+template <int B, int PL>
+__device__ __forceinline__ void block_fft_forward(double2 (&x)[1 << PL], double2* buf, const double2* ltw,
+                                                  const double2* __restrict__ gtw, uint32_t t) {
+  constexpr int Q = (B + PL - 1) / PL;
+  // the thread index is made opaque so that the many per-pass addresses are recomputed here
+  // (a few integer operations) instead of being hoisted out of the CMUX loop into registers
+  asm volatile("" : "+v"(t));
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    if (q > 0) exchange<PL>(x, buf, t, pass_lo(B, PL, q - 1), pass_lo(B, PL, q));
+    forward_stages<PL>(x, pass_lo(B, PL, q), B - 1 - q * PL, B, t, q == 0, gtw, ltw);
+  }
+}
+
+// exact mirror of block_fft_forward: same passes in reverse order
+template <int B, int PL>
+__device__ __forceinline__ void block_fft_inverse(double2 (&x)[1 << PL], double2* buf, const double2* ltw,
+                                                  const double2* __restrict__ gtw, uint32_t t) {
+  constexpr int Q = (B + PL - 1) / PL;
+  asm volatile("" : "+v"(t));
+#pragma unroll
+  for (int q = Q - 1; q >= 0; q--) {
+    inverse_stages<PL>(x, pass_lo(B, PL, q), B - 1 - q * PL, B, t, q == 0, gtw, ltw);
+    if (q > 0) exchange<PL>(x, buf, t, pass_lo(B, PL, q), pass_lo(B, PL, q - 1));
+  }
+}
+
+// per-stage compact copy of the stage twiddles of every pass but the first: stage b at [2^b - 1, 2^(b+1) - 1)
+__device__ __forceinline__ void fill_lds_twiddles(double2* ltw, const double2* __restrict__ gtw, uint32_t B,
+                                                  uint32_t stages) {
+  for (uint32_t e = threadIdx.x; e + 1 < (1u << stages); e += blockDim.x) {
+    const uint32_t b = 31u - __clz(e + 1u);
+    const uint32_t j = e + 1u - (1u << b);
+    ltw[e] = gtw[(size_t)j << (B - 1u - b)];
+  }
+}
+
+template <typename T, int B, int PL>
+__global__ __launch_bounds__(1 << (B - PL)) void block_bsk_fourier_kernel(const T* __restrict__ bsk,
+                                                                          double2* __restrict__ out,
+                                                                          const double2* __restrict__ tables) {
+  using S = typename Torus<T>::Signed;
+  constexpr int P = 1 << PL;
+  extern __shared__ double2 lds[];
+  constexpr uint32_t M = 1u << B, N = 2 * M, Tn = 1u << (B - PL);
+  const uint32_t t = threadIdx.x;
+  double2* buf = lds;
+  double2* ltw = lds + M;
+  const double2* twist = tables;
+  const double2* gtw = tables + M;
+  fill_lds_twiddles(ltw, gtw, B, B - PL);
+  const T* poly = bsk + (size_t)blockIdx.x * N;
+  const double scale = (Torus<T>::BITS == 64) ? 0x1.0p-64 : 0x1.0p-32;
+  double2 x[P];
+#pragma unroll
+  for (int r = 0; r < P; r++) {
+    const uint32_t j = (uint32_t)r * Tn + t;
+    const double re = signed_to_double((S)poly[j]) * scale;
+    const double im = signed_to_double((S)poly[j + M]) * scale;
+    x[r] = cmul(make_double2(re, im), twist[j]);
+  }
+  block_fft_forward<B, PL>(x, buf, ltw, gtw, t);
+  double2* dst = out + (size_t)blockIdx.x * M;
+#pragma unroll
+  for (int r = 0; r < P; r++) dst[(uint32_t)r * Tn + t] = x[r];
+}
+
+// number of Fourier-sum columns kept in registers; the others live in the workgroup's global
+// slab (N >= 8192: two columns of 16 points do not fit 256 registers next to the transform)
+constexpr int block_reg_columns(int B, int KP1) { return B >= 12 ? 1 : KP1; }
+
+template <typename T, int B, int PL, int KP1, int LV>
+__global__ __launch_bounds__(1 << (B - PL))
+__attribute__((amdgpu_waves_per_eu(block_waves(PL, block_reg_columns(B, KP1)))))
+void block_pbs_kernel(PbsLaunch<T> a) {
+  using S = typename Torus<T>::Signed;
+  constexpr int P = 1 << PL;
+  extern __shared__ double2 lds[];
+  constexpr uint32_t M = 1u << B, N = 2 * M, Tn = 1u << (B - PL);
+  const uint32_t tid = threadIdx.x;
+  uint32_t t = tid;
+  const uint32_t n = a.n, bl = a.base_log;
+  constexpr uint32_t L = LV;
+  constexpr uint32_t k = KP1 - 1;
+  constexpr uint32_t G = KP1 * N;
+  constexpr uint32_t logN = B + 1;
+  constexpr int CREG = block_reg_columns(B, KP1);
+  // points handled between two scheduling fences in the load-heavy phases: bounds the registers
+  // the compiler may spend on loads in flight
+  constexpr int GROUP = 4;
+  double2* buf = lds;
+  double2* ltw = lds + M;
+  const double2* twist = a.tables;
+  const double2* gtw = a.tables + M;
+  fill_lds_twiddles(ltw, gtw, B, B - PL);
+
+  constexpr size_t ST_BYTES = L > 1 ? (size_t)G * sizeof(uint32_t) : 0;
+  constexpr size_t SLAB = (size_t)G * sizeof(T) + ST_BYTES + (size_t)(KP1 - CREG) * M * sizeof(double2);
+  char* my = (char*)a.scratch + (size_t)blockIdx.x * SLAB;
+  T* ct0 = (T*)my;                                         // [(k+1)][N]
+  uint32_t* st = (uint32_t*)(my + (size_t)G * sizeof(T));  // [(k+1)][2P][Tn], decomposer states
+  double2* accg = (double2*)(my + (size_t)G * sizeof(T) + ST_BYTES);  // [KP1-CREG][P][Tn]
+  const double inv_m = 1.0 / (double)M;
+
+  for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
+    const T* in = a.ct_in + ct * a.in_stride;
+    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
+    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * G;
+
+    // ct0 <- lut * X^{-b_hat}
+    const uint32_t b_hat = modswitch<T>(in[n], logN);
+    const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+    for (uint32_t idx = tid; idx < G; idx += Tn) {
+      const uint32_t c = idx / N, j = idx - c * N;
+      ct0[idx] = rotated_coeff<T>(lut + (size_t)c * N, j, d0, N);
+    }
+    __syncthreads();
+
+    for (uint32_t i = 0; i < n; i++) {
+      const T ai = in[i];
+      if (ai == 0) continue;  // uniform over the workgroup
+      const uint32_t a_hat = modswitch<T>(ai, logN) & (2 * N - 1);
+      double2 accf[CREG][P];
+#pragma unroll 1
+      for (uint32_t l = L; l >= 1; l--) {
+#pragma unroll 1
+        for (uint32_t r = 0; r <= k; r++) {
+          // opaque copies: the addresses derived from them are recomputed per row (a few integer
+          // operations) instead of being hoisted out of the loops and kept live in registers
+          uint32_t a_rot = a_hat;
+          asm volatile("" : "+v"(t), "+v"(a_rot));
+          const T* p = ct0 + (size_t)r * N;
+          uint32_t* str = st + (size_t)r * N;
+          double2 x[P];
+          if (l == L) {
+            // rotated difference of row r, first (finest) digit; the rest of the state is parked
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+              const uint32_t j = (uint32_t)q * Tn + t;
+              const T x0 = rotated_coeff<T>(p, j, a_rot, N) - p[j];
+              const T x1 = rotated_coeff<T>(p, j + M, a_rot, N) - p[j + M];
+              T s0 = decomp_init_state<T>(x0, bl, L);
+              T s1 = decomp_init_state<T>(x1, bl, L);
+              const S g0 = decomp_next<T>(s0, bl);
+              const S g1 = decomp_next<T>(s1, bl);
+              if constexpr (L > 1) {
+                str[(uint32_t)(2 * q) * Tn + t] = (uint32_t)s0;
+                str[(uint32_t)(2 * q + 1) * Tn + t] = (uint32_t)s1;
+              }
+              x[q] = cmul(make_double2(signed_to_double(g0), signed_to_double(g1)), twist[j]);
+              if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+              const uint32_t j = (uint32_t)q * Tn + t;
+              T s0 = (T)str[(uint32_t)(2 * q) * Tn + t];
+              T s1 = (T)str[(uint32_t)(2 * q + 1) * Tn + t];
+              const S g0 = decomp_next<T>(s0, bl);
+              const S g1 = decomp_next<T>(s1, bl);
+              if constexpr (L > 2) {  // with two levels the state is spent after this digit
+                str[(uint32_t)(2 * q) * Tn + t] = (uint32_t)s0;
+                str[(uint32_t)(2 * q + 1) * Tn + t] = (uint32_t)s1;
+              }
+              x[q] = cmul(make_double2(signed_to_double(g0), signed_to_double(g1)), twist[j]);
+              if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          block_fft_forward<B, PL>(x, buf, ltw, gtw, t);
+          asm volatile("" : "+v"(t));
+          const double2* rows = a.fbsk + ((((size_t)i * L + (l - 1)) * KP1 + r) * KP1) * M;
+          if (l == L && r == 0) {
+#pragma unroll
+            for (int c = 0; c < KP1; c++) {
+#pragma unroll
+              for (int q = 0; q < P; q++) {
+                const double2 v = cmul(rows[(size_t)c * M + (uint32_t)q * Tn + t], x[q]);
+                if (c < CREG) accf[c < CREG ? c : 0][q] = v;
+                else accg[(size_t)(c - CREG) * M + (uint32_t)q * Tn + t] = v;
+                if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < KP1; c++) {
+#pragma unroll
+              for (int q = 0; q < P; q++) {
+                const double2 w = rows[(size_t)c * M + (uint32_t)q * Tn + t];
+                if (c < CREG) {
+                  accf[c < CREG ? c : 0][q] = cfma(w, x[q], accf[c < CREG ? c : 0][q]);
+                } else {
+                  double2* slot = accg + (size_t)(c - CREG) * M + (uint32_t)q * Tn + t;
+                  *slot = cfma(w, x[q], *slot);
+                }
+                if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+        }
+      }
+      // every gather of this CMUX is done (each thread reads coefficients other threads update)
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < KP1; c++) {
+        double2 x[P];
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int q = 0; q < P; q++)
+          x[q] = (c < CREG) ? accf[c < CREG ? c : 0][q] : accg[(size_t)(c - CREG) * M + (uint32_t)q * Tn + t];
+        block_fft_inverse<B, PL>(x, buf, ltw, gtw, t);
+        asm volatile("" : "+v"(t));
+        T* p = ct0 + (size_t)c * N;
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+          const uint32_t j = (uint32_t)q * Tn + t;
+          const double2 v = cmul_conj(x[q], twist[j]);
+          p[j] += from_torus_faithful<T>(v.x * inv_m);
+          p[j + M] += from_torus_faithful<T>(v.y * inv_m);
+          if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    }
+
+    // sample extraction of coefficient 0
+    T* out = a.ct_out + ct * a.out_stride;
+    for (uint32_t idx = tid; idx < k * N; idx += Tn) {
+      const uint32_t c = idx / N, j = idx - c * N;
+      const T* p = ct0 + (size_t)c * N;
+      out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
+    }
+    if (tid == 0) out[(size_t)k * N] = ct0[(size_t)k * N];
+    __syncthreads();
+  }
+}
+
+int block_pl(uint32_t N) { return N >= 8192 ? 4 : (N >= 1024 ? 3 : (N == 512 ? 2 : 1)); }
+
+size_t block_lds_bytes(uint32_t N) {
+  const uint32_t M = N / 2;
+  return ((size_t)M + (M >> block_pl(N))) * sizeof(double2);
+}
+
+template <typename T, int B, int PL, int KP1, int LV>
+int block_launch_levels(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream) {
+  const size_t lds = block_lds_bytes(a.N);
+  if (lds > 64 * 1024)
+    CAMD_HIP(hipFuncSetAttribute((const void*)block_pbs_kernel<T, B, PL, KP1, LV>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((block_pbs_kernel<T, B, PL, KP1, LV>), dim3(grid), dim3(1u << (B - PL)), lds, stream, a);
+  CAMD_HIP(hipGetLastError());
+  return CAMD_OK;
+}
+
+// LMASK: bit (L-1) set for every level count this (N, k) pair is instantiated for
+template <typename T, int B, int PL, int KP1, int LMASK>
+int block_launch_instance(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream) {
+  if constexpr (LMASK & 1) if (a.level == 1) return block_launch_levels<T, B, PL, KP1, 1>(a, grid, stream);
+  if constexpr (LMASK & 2) if (a.level == 2) return block_launch_levels<T, B, PL, KP1, 2>(a, grid, stream);
+  if constexpr (LMASK & 4) if (a.level == 3) return block_launch_levels<T, B, PL, KP1, 3>(a, grid, stream);
+  return fail(CAMD_EINVAL, "the register-blocked kernel has no instance for this level count");
+}
+
+template <typename T, int B, int PL>
+int block_fourier_instance(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream) {
+  const size_t lds = block_lds_bytes(2u << B);
+  if (lds > 64 * 1024)
+    CAMD_HIP(hipFuncSetAttribute((const void*)block_bsk_fourier_kernel<T, B, PL>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((block_bsk_fourier_kernel<T, B, PL>), dim3((unsigned)polys), dim3(1u << (B - PL)), lds, stream,
+                     bsk_std, fbsk, tables);
+  CAMD_HIP(hipGetLastError());
+  return CAMD_OK;
+}
+
+}  // namespace
+
+// instances: the (N, k) pairs of the reference's parameter sets
+bool block_supported(const camd_params& p) {
+  const uint32_t N = p.polynomial_size, k = p.glwe_dimension;
+  const uint32_t L = p.pbs_level;
+  if (p.torus_bits == 64) {
+    switch (N) {
+      case 256: return (k == 5 || k == 6) && L == 1;
+      case 512: return k == 3 && L == 1;
+      case 1024: return k == 2 && L == 1;
+      case 2048: return k == 1 && L == 1;
+      case 4096: case 8192: return k == 1 && (L == 1 || L == 2);
+      case 16384: return k == 1 && (L == 2 || L == 3);
+      default: return false;
+    }
+  }
+  return (N == 512 && k == 2 && L == 2) || (N == 1024 && k == 1 && L == 3);
+}
+
+size_t block_scratch_bytes(const camd_params& p, unsigned* grid_out, size_t count) {
+  const uint32_t N = p.polynomial_size, kp1 = p.glwe_dimension + 1;
+  const int Bits = (int)ilog2(N / 2);
+  const int creg = block_reg_columns(Bits, (int)kp1);
+  const size_t slab = (size_t)kp1 * N * (p.torus_bits / 8) + (p.pbs_level > 1 ? (size_t)kp1 * N * sizeof(uint32_t) : 0) +
+                      (size_t)(kp1 - creg) * (N / 2) * sizeof(double2);
+  const size_t threads = (N / 2) >> block_pl(N);
+  size_t per_cu = (size_t)block_waves(block_pl(N), creg) * 256 / threads;  // register budget of the instance
+  const size_t by_lds = (160 * 1024) / block_lds_bytes(N);
+  if (per_cu > by_lds) per_cu = by_lds;
+  if (per_cu < 1) per_cu = 1;
+  size_t grid = 256 * per_cu;
+  if (grid > count) grid = count;
+  if (grid < 1) grid = 1;
+  *grid_out = (unsigned)grid;
+  return slab * grid;
+}
+
+template <typename T>
+int block_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, uint32_t N, size_t polys,
+                         hipStream_t stream) {
+  switch (N) {
+    case 256: return block_fourier_instance<T, 7, 1>(bsk_std, fbsk, tables, polys, stream);
+    case 512: return block_fourier_instance<T, 8, 2>(bsk_std, fbsk, tables, polys, stream);
+    case 1024: return block_fourier_instance<T, 9, 3>(bsk_std, fbsk, tables, polys, stream);
+    case 2048: return block_fourier_instance<T, 10, 3>(bsk_std, fbsk, tables, polys, stream);
+    case 4096: return block_fourier_instance<T, 11, 3>(bsk_std, fbsk, tables, polys, stream);
+    case 8192: return block_fourier_instance<T, 12, 4>(bsk_std, fbsk, tables, polys, stream);
+    case 16384: return block_fourier_instance<T, 13, 4>(bsk_std, fbsk, tables, polys, stream);
+  }
+  return fail(CAMD_EINVAL, "the register-blocked kernel has no instance for this polynomial size");
+}
+
+template <typename T>
+int block_launch_pbs(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream) {
+  if (a.count == 0) return CAMD_OK;
+  const uint32_t N = a.N, kp1 = a.k + 1;
+  if constexpr (sizeof(T) == 8) {
+    if (N == 256 && kp1 == 6) return block_launch_instance<T, 7, 1, 6, 1>(a, grid, stream);
+    if (N == 256 && kp1 == 7) return block_launch_instance<T, 7, 1, 7, 1>(a, grid, stream);
+    if (N == 512 && kp1 == 4) return block_launch_instance<T, 8, 2, 4, 1>(a, grid, stream);
+    if (N == 1024 && kp1 == 3) return block_launch_instance<T, 9, 3, 3, 1>(a, grid, stream);
+    if (N == 2048 && kp1 == 2) return block_launch_instance<T, 10, 3, 2, 1>(a, grid, stream);
+    if (N == 4096 && kp1 == 2) return block_launch_instance<T, 11, 3, 2, 3>(a, grid, stream);
+    if (N == 8192 && kp1 == 2) return block_launch_instance<T, 12, 4, 2, 3>(a, grid, stream);
+    if (N == 16384 && kp1 == 2) return block_launch_instance<T, 13, 4, 2, 6>(a, grid, stream);
+  } else {
+    if (N == 512 && kp1 == 3) return block_launch_instance<T, 8, 2, 3, 2>(a, grid, stream);
+    if (N == 1024 && kp1 == 2) return block_launch_instance<T, 9, 3, 2, 4>(a, grid, stream);
+  }
+  return fail(CAMD_EINVAL, "the register-blocked kernel has no instance for this parameter set");
+}
+
+template int block_bsk_to_fourier<uint64_t>(const uint64_t*, double2*, const double2*, uint32_t, size_t, hipStream_t);
+template int block_bsk_to_fourier<uint32_t>(const uint32_t*, double2*, const double2*, uint32_t, size_t, hipStream_t);
+template int block_launch_pbs<uint64_t>(const PbsLaunch<uint64_t>&, unsigned, hipStream_t);
+template int block_launch_pbs<uint32_t>(const PbsLaunch<uint32_t>&, unsigned, hipStream_t);
+
+}  // namespace camd

@@ -57,6 +57,7 @@ typedef struct camd_params {
 #define CAMD_PBS_AUTO 0
 #define CAMD_PBS_GENERIC 1
 #define CAMD_PBS_WAVE 2
+#define CAMD_PBS_BLOCK 3
 
 const char* camd_last_error(void);
 /* library version string */
@@ -78,7 +79,7 @@ int camd_server_key_create(camd_context* ctx, const camd_params* params, const v
                            const void* ksk, int pbs_variant, camd_server_key** out);
 int camd_server_key_destroy(camd_server_key* key);
 int camd_server_key_params(const camd_server_key* key, camd_params* out);
-/* which bootstrap kernel family the key uses (CAMD_PBS_GENERIC or CAMD_PBS_WAVE) */
+/* which bootstrap kernel family the key uses (CAMD_PBS_GENERIC, CAMD_PBS_WAVE or CAMD_PBS_BLOCK) */
 int camd_server_key_variant(const camd_server_key* key, int* variant);
 
 /* Device-resident key material as one blob (Fourier bootstrap key, keyswitch key), so that a

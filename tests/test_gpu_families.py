@@ -1,7 +1,8 @@
 """GPU parity across parameter families and edge cases, through the C ABI.
 
-The workgroup-per-ciphertext kernel covers every parameter set and performs the oracle's exact
-sequence of IEEE-754 operations, so outputs are compared bit for bit. The LWE dimension is
+The two workgroup-per-ciphertext kernels (radix-2 fallback and register-blocked) cover every
+parameter set and perform the oracle's exact sequence of IEEE-754 operations, so outputs are
+compared bit for bit. The LWE dimension is
 shortened (n = 6..24 CMUX iterations instead of 567..991): the kernels are the same, the loop is
 shorter, and the oracle finishes in seconds.
 """
@@ -11,7 +12,7 @@ import numpy as np
 import pytest
 
 import concrete_amd.parameters as P
-from concrete_amd.backend import CAMD_PBS_AUTO, CAMD_PBS_GENERIC, CAMD_PBS_WAVE, DeviceServerKey
+from concrete_amd.backend import CAMD_PBS_AUTO, CAMD_PBS_BLOCK, CAMD_PBS_GENERIC, CAMD_PBS_WAVE, DeviceServerKey
 from oracle import cpu_oracle as O
 from conftest import get_keys
 
@@ -34,12 +35,17 @@ SHORTINT_FAMILIES = [
 ]
 
 
+EXACT_VARIANTS = [CAMD_PBS_GENERIC, CAMD_PBS_BLOCK]
+
+
+@pytest.mark.parametrize("variant", EXACT_VARIANTS)
 @pytest.mark.parametrize("pname,n", SHORTINT_FAMILIES)
-def test_ks_pbs_bit_exact_every_family(gpu_ctx, pname, n):
+def test_ks_pbs_bit_exact_every_family(gpu_ctx, pname, n, variant):
     p = P.SHORTINT_BY_NAME[pname]
     ks = get_keys(p, 64, n_override=n)
     o = ks.o
-    dk = device_key(gpu_ctx, ks)
+    dk = device_key(gpu_ctx, ks, variant)
+    assert dk.variant == variant
     msg, sup = p.message_modulus, p.message_modulus * p.carry_modulus
     fs = [lambda x: x % msg, lambda x: x // msg]
     luts = [o.generate_accumulator(f) for f in fs]
@@ -60,12 +66,13 @@ def test_ks_pbs_bit_exact_every_family(gpu_ctx, pname, n):
     dk.close()
 
 
+@pytest.mark.parametrize("variant", EXACT_VARIANTS)
 @pytest.mark.parametrize("params", [P.DEFAULT_PARAMETERS, P.TFHE_LIB_PARAMETERS])
-def test_boolean_pbs_ks_bit_exact(gpu_ctx, params):
+def test_boolean_pbs_ks_bit_exact(gpu_ctx, params, variant):
     """32-bit torus, bootstrap then keyswitch (concrete-boolean cpu.rs:215-259)."""
     ks = get_keys(params, 32, n_override=16)
     o = ks.o
-    dk = device_key(gpu_ctx, ks)
+    dk = device_key(gpu_ctx, ks, variant)
     acc = o.boolean_accumulator()
     dk.upload_lut(acc)
     T, F = 1 << 29, 7 << 29
@@ -109,15 +116,15 @@ def test_full_size_boolean_nand_truth_table(gpu_ctx):
     cts = np.stack(rows)
     got = dk.pbs_ks(cts)
     want = o.pbs_ks_batch(ks.ksk, ks.fbsk, acc, None, cts, threads=8)
-    if dk.variant == CAMD_PBS_GENERIC:
-        assert np.array_equal(got, want)
+    assert dk.variant == CAMD_PBS_BLOCK
+    assert np.array_equal(got, want)
     for i, bit in enumerate(want_bits):
         assert (o.lwe_phase(ks.small, got[i]) < (1 << 31)) == bit
         assert (o.lwe_phase(ks.small, want[i]) < (1 << 31)) == bit
     dk.close()
 
 
-@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC, CAMD_PBS_WAVE])
+@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC, CAMD_PBS_BLOCK, CAMD_PBS_WAVE])
 def test_edge_cases_2_2(gpu_ctx, variant):
     """Empty batch, ragged batch sizes, aliasing of input and output, trivial inputs, lut ids."""
     p = P.PARAM_MESSAGE_2_CARRY_2
@@ -138,7 +145,7 @@ def test_edge_cases_2_2(gpu_ctx, variant):
         ids = (np.arange(count) % 3).astype(np.uint32)
         got = dk.ks_pbs(cts, ids)
         want = o.ks_pbs_batch(ks.ksk, ks.fbsk, np.concatenate(luts), ids, cts, threads=4)
-        if variant == CAMD_PBS_GENERIC:
+        if variant in EXACT_VARIANTS:
             assert np.array_equal(got, want)
         assert np.array_equal(got[0], want[0])  # trivial input: exact in every family
         for i in range(count):
