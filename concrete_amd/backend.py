@@ -30,6 +30,20 @@ class Context:
     def synchronize(self) -> None:
         check(_ffi.lib().camd_context_synchronize(self._h))
 
+    def lwe_axpby_device(self, out, x, alpha: int, y=None, beta: int = 0, body_add: int = 0, torus_bits: int = 64,
+                         stream: int = 0) -> None:
+        """out = alpha*x + beta*y (+ body_add on the last word of each row), wrapping, on the GPU.
+        ``out``, ``x``, ``y`` are 2-D torch CUDA tensors [count][words] whose rows may be strided
+        (a block of a radix batch is such a view); the last dimension must be contiguous."""
+        for t in (out, x) + ((y,) if y is not None else ()):
+            if t.dim() != 2 or t.stride(1) != 1 or t.shape != out.shape or t.element_size() * 8 != torus_bits:
+                raise ValueError("lwe_axpby_device: tensors must be [count][words] of the torus width, rows contiguous")
+        mask = (1 << 64) - 1
+        check(_ffi.lib().camd_lwe_axpby_device(
+            self._h, int(torus_bits), C.c_void_p(out.data_ptr()), out.stride(0), C.c_void_p(x.data_ptr()), x.stride(0),
+            int(alpha) & mask, C.c_void_p(y.data_ptr()) if y is not None else None, y.stride(0) if y is not None else 0,
+            int(beta) & mask, int(body_add) & mask, out.shape[1], out.shape[0], C.c_void_p(stream)))
+
     def close(self) -> None:
         if self._h:
             _ffi.lib().camd_context_destroy(self._h)

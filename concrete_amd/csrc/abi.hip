@@ -550,6 +550,23 @@ int camd_ks_batch_device(camd_server_key* key, const void* ct_in, void* ct_out, 
   return dispatch_device(key, Op::Ks, ct_in, nullptr, ct_out, count, stream);
 }
 
+int camd_lwe_axpby_device(camd_context* ctx, uint32_t torus_bits, void* out, size_t out_stride, const void* x,
+                          size_t x_stride, uint64_t alpha, const void* y, size_t y_stride, uint64_t beta, uint64_t body_add,
+                          size_t words, size_t count, void* stream) {
+  if (!ctx || (count && words && (!out || !x))) return fail(CAMD_EINVAL, "null argument");
+  if (torus_bits != 32 && torus_bits != 64) return fail(CAMD_EINVAL, "torus_bits must be 32 or 64");
+  if (count && words && (out_stride < words || x_stride < words || (y && y_stride < words)))
+    return fail(CAMD_EINVAL, "row stride shorter than the ciphertext");
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
+  hipStream_t s = (hipStream_t)stream;
+  if (torus_bits == 64)
+    return launch_lwe_axpby<uint64_t>((uint64_t*)out, out_stride, (const uint64_t*)x, x_stride, alpha, (const uint64_t*)y,
+                                      y_stride, beta, body_add, words, count, s);
+  return launch_lwe_axpby<uint32_t>((uint32_t*)out, out_stride, (const uint32_t*)x, x_stride, (uint32_t)alpha,
+                                    (const uint32_t*)y, y_stride, (uint32_t)beta, (uint32_t)body_add, words, count, s);
+}
+
 int camd_timing_enable(camd_server_key* key, int enable) {
   if (!key) return fail(CAMD_EINVAL, "null key");
   DeviceGuard g(key->ctx->device);

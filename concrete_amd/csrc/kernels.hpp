@@ -1,6 +1,8 @@
 // Launcher declarations shared by the C ABI layer and the kernel translation units.
 #pragma once
 
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace camd {
@@ -27,6 +29,11 @@ template <typename T>
 int launch_keyswitch(const T* ct_in, size_t in_stride, T* ct_out, size_t out_stride, const T* ksk,
                      uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level, size_t count,
                      hipStream_t stream);
+
+// ---- leveled operations on device ciphertexts (linear.hip) ----
+template <typename T>
+int launch_lwe_axpby(T* out, size_t out_stride, const T* x, size_t x_stride, T alpha, const T* y, size_t y_stride, T beta,
+                     T body_add, size_t words, size_t count, hipStream_t stream);
 
 // ---- workgroup-per-ciphertext bootstrap, any parameter set (pbs_generic.hip) ----
 // tables: twist[M] then stage twiddles W_M^j for j < M/2 (host fills them in double precision)

@@ -1,0 +1,547 @@
+"""Host-side mirror of concrete-integer's radix layer, driven through the GPU shortint backend.
+
+* ``ClientKey`` / ``RadixClientKey`` — ``concrete-integer/src/client_key/{mod,radix}.rs``
+* ``RadixCiphertext``               — ``concrete-integer/src/ciphertext/mod.rs:8-15``: blocks in
+  base ``message_modulus``, least significant first
+* ``ServerKey``                     — ``concrete-integer/src/server_key/{mod,radix/*,radix_parallel/*}.rs``
+
+The algorithms (carry propagation, schoolbook block multiplication, tree reduction, degree-driven
+"smart" operations) are the reference's. What changes is how their bootstraps reach the
+hardware: every block of a ``RadixCiphertext`` here may be a *batch* (the same block of many
+integers, host or device resident), and bootstraps that are independent of each other — the two
+extractions of a propagation step, the lsb/msb products of every block pair of a multiplication,
+the blocks of a bitwise operation — are collected and issued as one launch
+(``shortint.ServerKey.deferred``). The ``*_parallelized`` names of the reference are therefore
+aliases: there is one schedule, and it is the batched one.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Iterable, List
+
+import numpy as np
+
+from . import shortint as _si
+from .backend import CAMD_PBS_AUTO, Context
+from .shortint_ops import CheckError
+
+
+@dataclass
+class RadixCiphertext:
+    """ciphertext/mod.rs:8-15."""
+    blocks: List[_si.Ciphertext]
+
+    def clone(self) -> "RadixCiphertext":
+        return RadixCiphertext([b.clone() for b in self.blocks])
+
+    @property
+    def count(self) -> int:
+        return self.blocks[0].count
+
+    def to_device(self, device="cuda") -> "RadixCiphertext":
+        return RadixCiphertext([b.to_device(device) for b in self.blocks])
+
+    def to_host(self) -> "RadixCiphertext":
+        return RadixCiphertext([b.to_host() for b in self.blocks])
+
+
+class ClientKey:
+    """client_key/mod.rs:25-93."""
+
+    def __init__(self, parameters, seed: int = 0):
+        self.key = _si.ClientKey(parameters, seed)
+
+    @classmethod
+    def new(cls, parameters, seed: int = 0) -> "ClientKey":
+        return cls(parameters, seed)
+
+    def parameters(self):
+        return self.key.parameters
+
+    def _digits(self, message: int, num_blocks: int) -> list[int]:
+        # client_key/mod.rs:98-111: digit i = (message & (mask * power)) / power, all in u64
+        modulus = self.key.parameters.message_modulus
+        mask = modulus - 1
+        message = int(message) & 0xFFFFFFFFFFFFFFFF
+        return [(message & (mask * modulus ** i)) // modulus ** i for i in range(num_blocks)]
+
+    def encrypt_radix(self, message: int, num_blocks: int) -> RadixCiphertext:
+        """client_key/mod.rs:95-114."""
+        return RadixCiphertext([self.key.encrypt(d) for d in self._digits(message, num_blocks)])
+
+    def encrypt_radix_many(self, messages: Iterable[int], num_blocks: int, device=None) -> RadixCiphertext:
+        """A batch of integers: block i of the result holds digit i of every message."""
+        digits = [self._digits(m, num_blocks) for m in messages]
+        blocks = [self.key.encrypt_many([d[i] for d in digits]) for i in range(num_blocks)]
+        ct = RadixCiphertext(blocks)
+        return ct.to_device(device) if device is not None else ct
+
+    def decrypt_radix(self, ctxt: RadixCiphertext):
+        """client_key/mod.rs:215-234: blocks are decrypted with their carries and recombined."""
+        modulus = self.key.parameters.message_modulus
+        whole = modulus ** len(ctxt.blocks)
+        vals = [self.key.decrypt_message_and_carry(b) for b in ctxt.blocks]
+        if np.ndim(vals[0]) == 0:
+            return sum(int(v) * modulus ** i for i, v in enumerate(vals)) % whole
+        total = np.zeros(len(vals[0]), dtype=object)
+        for i, v in enumerate(vals):
+            total = total + v.astype(object) * (modulus ** i)
+        return np.array([int(t) % whole for t in total], dtype=np.uint64)
+
+
+class RadixClientKey(ClientKey):
+    """client_key/radix.rs: a client key that remembers the number of blocks."""
+
+    def __init__(self, parameters, num_blocks: int, seed: int = 0):
+        super().__init__(parameters, seed)
+        self.num_blocks = int(num_blocks)
+
+    def encrypt(self, message: int) -> RadixCiphertext:
+        return self.encrypt_radix(message, self.num_blocks)
+
+    def encrypt_many(self, messages: Iterable[int], device=None) -> RadixCiphertext:
+        return self.encrypt_radix_many(messages, self.num_blocks, device)
+
+    def decrypt(self, ctxt: RadixCiphertext):
+        return self.decrypt_radix(ctxt)
+
+
+class ServerKey:
+    """server_key/mod.rs:24-68: a shortint server key whose max_degree leaves room for one carry."""
+
+    def __init__(self, key: _si.ServerKey):
+        p = key.parameters
+        key.max_degree = (p.message_modulus - 1) * p.carry_modulus - 1
+        self.key = key
+
+    @classmethod
+    def new(cls, cks: ClientKey, ctx: Context | None = None, variant: int = CAMD_PBS_AUTO) -> "ServerKey":
+        return cls(_si.ServerKey.new(cks.key, ctx=ctx, variant=variant))
+
+    @classmethod
+    def from_shortint(cls, cks: ClientKey, key: _si.ServerKey) -> "ServerKey":
+        return cls(key)
+
+    # ------------------------------------------------------------- radix/mod.rs --
+    def create_trivial_zero_radix(self, num_blocks: int, like: RadixCiphertext | None = None) -> RadixCiphertext:
+        ref = like.blocks[0] if like is not None else None
+        return RadixCiphertext([self.key.create_trivial(0, like=ref) for _ in range(num_blocks)])
+
+    def _propagate_many(self, pairs) -> None:
+        """One propagation step on several (ciphertext, index) pairs whose results do not depend
+        on each other: all carry and message extractions in one launch, then the carry adds."""
+        carries = []
+        with self.key.deferred():
+            for ctxt, index in pairs:
+                carry = self.key.carry_extract(ctxt.blocks[index])
+                self.key.message_extract_assign(ctxt.blocks[index])
+                carries.append(carry)
+        for (ctxt, index), carry in zip(pairs, carries):
+            if index < len(ctxt.blocks) - 1:
+                self.key.unchecked_add_assign(ctxt.blocks[index + 1], carry)
+
+    def propagate(self, ctxt: RadixCiphertext, index: int) -> None:
+        """radix/mod.rs:58-68 (radix_parallel/mod.rs:17-31 runs the two extractions side by side;
+        here they are one launch)."""
+        self._propagate_many([(ctxt, index)])
+
+    def full_propagate(self, ctxt: RadixCiphertext) -> None:
+        """radix/mod.rs:95-101: the carry chain is inherently sequential over the blocks."""
+        for i in range(len(ctxt.blocks)):
+            self.propagate(ctxt, i)
+
+    def _full_propagate_many(self, ctxts) -> None:
+        """full_propagate of independent integers, block step by block step (rayon::join in
+        radix_parallel/add.rs:14-19, mul.rs:163-166)."""
+        ctxts = list(ctxts)
+        if not ctxts:
+            return
+        for i in range(max(len(c.blocks) for c in ctxts)):
+            self._propagate_many([(c, i) for c in ctxts if i < len(c.blocks)])
+
+    propagate_parallelized = propagate
+    full_propagate_parallelized = full_propagate
+
+    # ------------------------------------------------------------------- add.rs --
+    def unchecked_add(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> RadixCiphertext:
+        res = lhs.clone()
+        self.unchecked_add_assign(res, rhs)
+        return res
+
+    def unchecked_add_assign(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> None:
+        for a, b in zip(lhs.blocks, rhs.blocks):
+            self.key.unchecked_add_assign(a, b)
+
+    def is_add_possible(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> bool:
+        return all(self.key.is_add_possible(a, b) for a, b in zip(lhs.blocks, rhs.blocks))
+
+    def checked_add(self, lhs, rhs) -> RadixCiphertext:
+        if not self.is_add_possible(lhs, rhs):
+            raise CheckError()
+        return self.unchecked_add(lhs, rhs)
+
+    def checked_add_assign(self, lhs, rhs) -> None:
+        if not self.is_add_possible(lhs, rhs):
+            raise CheckError()
+        self.unchecked_add_assign(lhs, rhs)
+
+    def smart_add(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> RadixCiphertext:
+        """radix/add.rs:205-217; both operands are propagated together."""
+        if not self.is_add_possible(lhs, rhs):
+            self._full_propagate_many([lhs, rhs])
+        return self.unchecked_add(lhs, rhs)
+
+    def smart_add_assign(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> None:
+        if not self.is_add_possible(lhs, rhs):
+            self._full_propagate_many([lhs, rhs])
+        self.unchecked_add_assign(lhs, rhs)
+
+    smart_add_parallelized = smart_add
+    smart_add_assign_parallelized = smart_add_assign
+
+    def smart_binary_op_seq_parallelized(self, ct_seq, op):
+        """radix_parallel/add.rs:55-140: pairwise tree reduction (an odd element stays in
+        front). Each level's operations are independent; their propagations share launches when
+        ``op`` is one of this class's smart operations."""
+        seq = list(ct_seq)
+        if not seq:
+            return None
+        while len(seq) > 1:
+            prefix = len(seq) % 2
+            pairs = [(seq[i], seq[i + 1]) for i in range(prefix, len(seq), 2)]
+            if op in (ServerKey.smart_add, ServerKey.smart_add_parallelized):
+                need = [c for a, b in pairs if not self.is_add_possible(a, b) for c in (a, b)]
+                self._full_propagate_many(need)
+                results = [self.unchecked_add(a, b) for a, b in pairs]
+            else:
+                results = [op(self, a, b) for a, b in pairs]
+            seq = seq[:prefix] + results
+        return seq[0]
+
+    # ------------------------------------------------------------ neg.rs, sub.rs --
+    def unchecked_neg(self, ctxt: RadixCiphertext) -> RadixCiphertext:
+        res = ctxt.clone()
+        self.unchecked_neg_assign(res)
+        return res
+
+    def unchecked_neg_assign(self, ctxt: RadixCiphertext) -> None:
+        """radix/neg.rs:56-72: block-wise negation; the correcting term of block i is paid back
+        as a scalar added to block i+1."""
+        n = len(ctxt.blocks)
+        for i in range(n):
+            z = self.key.unchecked_neg_assign_with_z(ctxt.blocks[i])
+            z_b = z // self.key.message_modulus
+            if i < n - 1:
+                self.key.unchecked_scalar_add_assign(ctxt.blocks[i + 1], z_b)
+
+    def is_neg_possible(self, ctxt: RadixCiphertext) -> bool:
+        return all(self.key.is_neg_possible(b) for b in ctxt.blocks)
+
+    def checked_neg(self, ctxt):
+        if not self.is_neg_possible(ctxt):
+            raise CheckError()
+        return self.unchecked_neg(ctxt)
+
+    def smart_neg(self, ctxt: RadixCiphertext) -> RadixCiphertext:
+        if not self.is_neg_possible(ctxt):
+            self.full_propagate(ctxt)
+        return self.unchecked_neg(ctxt)
+
+    smart_neg_parallelized = smart_neg
+
+    def unchecked_sub(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> RadixCiphertext:
+        res = lhs.clone()
+        self.unchecked_sub_assign(res, rhs)
+        return res
+
+    def unchecked_sub_assign(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> None:
+        """radix/sub.rs:57-64."""
+        self.unchecked_add_assign(lhs, self.unchecked_neg(rhs))
+
+    def is_sub_possible(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> bool:
+        return all(self.key.is_sub_possible(a, b) for a, b in zip(lhs.blocks, rhs.blocks))
+
+    def checked_sub(self, lhs, rhs):
+        if not self.is_sub_possible(lhs, rhs):
+            raise CheckError()
+        return self.unchecked_sub(lhs, rhs)
+
+    def checked_sub_assign(self, lhs, rhs) -> None:
+        if not self.is_sub_possible(lhs, rhs):
+            raise CheckError()
+        self.unchecked_sub_assign(lhs, rhs)
+
+    def smart_sub_assign(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> None:
+        """radix/sub.rs:233-248."""
+        if not self.is_neg_possible(rhs):
+            self.full_propagate(rhs)
+        if not self.is_sub_possible(lhs, rhs):
+            self._full_propagate_many([lhs, rhs])
+        self.unchecked_sub_assign(lhs, rhs)
+
+    def smart_sub(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> RadixCiphertext:
+        if not self.is_neg_possible(rhs):
+            self.full_propagate(rhs)
+        if not self.is_sub_possible(lhs, rhs):
+            self._full_propagate_many([lhs, rhs])
+        return self.unchecked_sub(lhs, rhs)
+
+    smart_sub_parallelized = smart_sub
+    smart_sub_assign_parallelized = smart_sub_assign
+
+    # ------------------------------------------------ scalar_add.rs, scalar_sub.rs --
+    def _scalar_digits(self, scalar: int, num_blocks: int) -> list[int]:
+        modulus = self.key.message_modulus
+        mask = modulus - 1
+        scalar = int(scalar) & 0xFFFFFFFFFFFFFFFF
+        return [((scalar & (mask * modulus ** i)) // modulus ** i) & 0xFF for i in range(num_blocks)]
+
+    def unchecked_scalar_add(self, ct: RadixCiphertext, scalar: int) -> RadixCiphertext:
+        res = ct.clone()
+        self.unchecked_scalar_add_assign(res, scalar)
+        return res
+
+    def unchecked_scalar_add_assign(self, ct: RadixCiphertext, scalar: int) -> None:
+        """radix/scalar_add.rs:52-66: the scalar is added digit by digit."""
+        for b, d in zip(ct.blocks, self._scalar_digits(scalar, len(ct.blocks))):
+            self.key.unchecked_scalar_add_assign(b, d)
+
+    def is_scalar_add_possible(self, ct: RadixCiphertext, scalar: int) -> bool:
+        return all(self.key.is_scalar_add_possible(b, d)
+                   for b, d in zip(ct.blocks, self._scalar_digits(scalar, len(ct.blocks))))
+
+    def checked_scalar_add(self, ct, scalar: int):
+        if not self.is_scalar_add_possible(ct, scalar):
+            raise CheckError()
+        return self.unchecked_scalar_add(ct, scalar)
+
+    def smart_scalar_add(self, ct: RadixCiphertext, scalar: int) -> RadixCiphertext:
+        if not self.is_scalar_add_possible(ct, scalar):
+            self.full_propagate(ct)
+        return self.unchecked_scalar_add(ct, scalar)
+
+    def smart_scalar_add_assign(self, ct: RadixCiphertext, scalar: int) -> None:
+        if not self.is_scalar_add_possible(ct, scalar):
+            self.full_propagate(ct)
+        self.unchecked_scalar_add_assign(ct, scalar)
+
+    smart_scalar_add_parallelized = smart_scalar_add
+    smart_scalar_add_assign_parallelized = smart_scalar_add_assign
+
+    def _neg_scalar(self, scalar: int, num_blocks: int) -> int:
+        modulus = self.key.message_modulus ** num_blocks
+        return ((-int(scalar)) & 0xFFFFFFFFFFFFFFFF) % modulus
+
+    def unchecked_scalar_sub(self, ct: RadixCiphertext, scalar: int) -> RadixCiphertext:
+        res = ct.clone()
+        self.unchecked_scalar_sub_assign(res, scalar)
+        return res
+
+    def unchecked_scalar_sub_assign(self, ct: RadixCiphertext, scalar: int) -> None:
+        """radix/scalar_sub.rs:49-66: adds the two's complement of the scalar."""
+        self.unchecked_scalar_add_assign(ct, self._neg_scalar(scalar, len(ct.blocks)))
+
+    def is_scalar_sub_possible(self, ct: RadixCiphertext, scalar: int) -> bool:
+        return self.is_scalar_add_possible(ct, self._neg_scalar(scalar, len(ct.blocks)))
+
+    def checked_scalar_sub(self, ct, scalar: int):
+        if not self.is_scalar_sub_possible(ct, scalar):
+            raise CheckError()
+        return self.unchecked_scalar_sub(ct, scalar)
+
+    def smart_scalar_sub(self, ct: RadixCiphertext, scalar: int) -> RadixCiphertext:
+        if not self.is_scalar_sub_possible(ct, scalar):
+            self.full_propagate(ct)
+        return self.unchecked_scalar_sub(ct, scalar)
+
+    def smart_scalar_sub_assign(self, ct: RadixCiphertext, scalar: int) -> None:
+        if not self.is_scalar_sub_possible(ct, scalar):
+            self.full_propagate(ct)
+        self.unchecked_scalar_sub_assign(ct, scalar)
+
+    smart_scalar_sub_parallelized = smart_scalar_sub
+    smart_scalar_sub_assign_parallelized = smart_scalar_sub_assign
+
+    # --------------------------------------------------------------- scalar_mul.rs --
+    def unchecked_small_scalar_mul(self, ctxt: RadixCiphertext, scalar: int) -> RadixCiphertext:
+        res = ctxt.clone()
+        self.unchecked_small_scalar_mul_assign(res, scalar)
+        return res
+
+    def unchecked_small_scalar_mul_assign(self, ctxt: RadixCiphertext, scalar: int) -> None:
+        for b in ctxt.blocks:
+            self.key.unchecked_scalar_mul_assign(b, int(scalar) & 0xFF)
+
+    def is_small_scalar_mul_possible(self, ctxt: RadixCiphertext, scalar: int) -> bool:
+        return all(self.key.is_scalar_mul_possible(b, int(scalar) & 0xFF) for b in ctxt.blocks)
+
+    def checked_small_scalar_mul(self, ctxt, scalar: int):
+        if not self.is_small_scalar_mul_possible(ctxt, scalar):
+            raise CheckError()
+        return self.unchecked_small_scalar_mul(ctxt, scalar)
+
+    def smart_small_scalar_mul(self, ctxt: RadixCiphertext, scalar: int) -> RadixCiphertext:
+        if not self.is_small_scalar_mul_possible(ctxt, scalar):
+            self.full_propagate(ctxt)
+        return self.unchecked_small_scalar_mul(ctxt, scalar)
+
+    def smart_small_scalar_mul_assign(self, ctxt: RadixCiphertext, scalar: int) -> None:
+        if not self.is_small_scalar_mul_possible(ctxt, scalar):
+            self.full_propagate(ctxt)
+        self.unchecked_small_scalar_mul_assign(ctxt, scalar)
+
+    def blockshift(self, ctxt: RadixCiphertext, shift: int) -> RadixCiphertext:
+        """radix/scalar_mul.rs:280-292: multiply by message_modulus^shift (high blocks fall off)."""
+        n = len(ctxt.blocks)
+        zero = self.key.create_trivial(0, like=ctxt.blocks[0])
+        return RadixCiphertext([zero.clone() for _ in range(min(shift, n))] + [b.clone() for b in ctxt.blocks[:n - shift]])
+
+    def blockshift_right(self, ctxt: RadixCiphertext, shift: int) -> RadixCiphertext:
+        """radix/shift.rs:33-46."""
+        n = len(ctxt.blocks)
+        zero = self.key.create_trivial(0, like=ctxt.blocks[0])
+        return RadixCiphertext([b.clone() for b in ctxt.blocks[shift:]] + [zero.clone() for _ in range(min(shift, n))])
+
+    def smart_scalar_mul(self, ctxt: RadixCiphertext, scalar: int) -> RadixCiphertext:
+        """radix/scalar_mul.rs:316-358: one small-scalar product per distinct non-trivial digit of
+        the scalar, shifted and summed."""
+        n = len(ctxt.blocks)
+        self.full_propagate(ctxt)
+        cache: dict[int, RadixCiphertext] = {}
+        result = self.create_trivial_zero_radix(n, like=ctxt)
+        for i, u_i in enumerate(self._scalar_digits(scalar, n)):
+            if u_i == 0:
+                continue
+            if u_i == 1:
+                tmp = self.blockshift(ctxt, i)
+            else:
+                if u_i not in cache:
+                    cache[u_i] = self.smart_small_scalar_mul(ctxt, u_i)
+                tmp = self.blockshift(cache[u_i], i)
+            result = self.smart_add(result, tmp)
+        return result
+
+    def smart_scalar_mul_assign(self, ctxt: RadixCiphertext, scalar: int) -> None:
+        ctxt.blocks = self.smart_scalar_mul(ctxt, scalar).blocks
+
+    smart_scalar_mul_parallelized = smart_scalar_mul
+
+    # ------------------------------------------------------------------- mul.rs --
+    def _block_mul_parts(self, ct1: RadixCiphertext, ct2_block: _si.Ciphertext, index: int):
+        """radix/mul.rs:54-76: low and high halves of ct1 * (one block of ct2), the bootstraps
+        left to the caller's ``deferred`` scope."""
+        shifted = self.blockshift(ct1, index)
+        lsb, msb = shifted.clone(), shifted
+        n = len(lsb.blocks)
+        for b in lsb.blocks[index:]:
+            self.key.unchecked_mul_lsb_assign(b, ct2_block)
+        for b in msb.blocks[index:n - 1]:
+            self.key.unchecked_mul_msb_assign(b, ct2_block)
+        return lsb, msb
+
+    def unchecked_block_mul(self, ct1: RadixCiphertext, ct2_block: _si.Ciphertext, index: int) -> RadixCiphertext:
+        with self.key.deferred():
+            lsb, msb = self._block_mul_parts(ct1, ct2_block, index)
+        return self.unchecked_add(lsb, self.blockshift(msb, 1))
+
+    def unchecked_block_mul_assign(self, ct1: RadixCiphertext, ct2_block: _si.Ciphertext, index: int) -> None:
+        ct1.blocks = self.unchecked_block_mul(ct1, ct2_block, index).blocks
+
+    def smart_block_mul(self, ct1: RadixCiphertext, ct2_block: _si.Ciphertext, index: int) -> RadixCiphertext:
+        """radix/mul.rs:113-139."""
+        self.full_propagate(ct1)
+        with self.key.deferred():
+            lsb, msb = self._block_mul_parts(ct1, ct2_block, index)
+        return self.smart_add(lsb, self.blockshift(msb, 1))
+
+    def smart_block_mul_assign(self, ct1: RadixCiphertext, ct2_block: _si.Ciphertext, index: int) -> None:
+        ct1.blocks = self.smart_block_mul(ct1, ct2_block, index).blocks
+
+    def _mul_terms(self, ct1: RadixCiphertext, ct2: RadixCiphertext) -> list[RadixCiphertext]:
+        """Every block product of the schoolbook multiplication, in ONE launch
+        (radix_parallel/mul.rs:111-125 spreads them over rayon workers)."""
+        with self.key.deferred():
+            parts = [self._block_mul_parts(ct1, b, i) for i, b in enumerate(ct2.blocks)]
+        return [self.unchecked_add(lsb, self.blockshift(msb, 1)) for lsb, msb in parts]
+
+    def unchecked_mul(self, ct1: RadixCiphertext, ct2: RadixCiphertext) -> RadixCiphertext:
+        """radix/mul.rs:186-200."""
+        result = self.create_trivial_zero_radix(len(ct1.blocks), like=ct1)
+        for term in self._mul_terms(ct1, ct2):
+            self.unchecked_add_assign(result, term)
+        return result
+
+    def unchecked_mul_assign(self, ct1: RadixCiphertext, ct2: RadixCiphertext) -> None:
+        ct1.blocks = self.unchecked_mul(ct1, ct2).blocks
+
+    def smart_mul(self, ct1: RadixCiphertext, ct2: RadixCiphertext) -> RadixCiphertext:
+        """radix_parallel/mul.rs:157-181 (radix/mul.rs:253-268 sums the terms one after the other;
+        the tree of the parallel form is used for both names)."""
+        self._full_propagate_many([ct1, ct2])
+        terms = self._mul_terms(ct1, ct2)
+        res = self.smart_binary_op_seq_parallelized(terms, ServerKey.smart_add)
+        return res if res is not None else self.create_trivial_zero_radix(len(ct1.blocks), like=ct1)
+
+    def smart_mul_assign(self, ct1: RadixCiphertext, ct2: RadixCiphertext) -> None:
+        ct1.blocks = self.smart_mul(ct1, ct2).blocks
+
+    unchecked_block_mul_parallelized = unchecked_block_mul
+    smart_block_mul_parallelized = smart_block_mul
+    unchecked_mul_parallelized = unchecked_mul
+    smart_mul_parallelized = smart_mul
+    smart_mul_assign_parallelized = smart_mul_assign
+
+    # ------------------------------------------------------------- bitwise_op.rs --
+    def is_functional_bivariate_pbs_possible(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> bool:
+        return all(self.key.is_functional_bivariate_pbs_possible(a, b) for a, b in zip(lhs.blocks, rhs.blocks))
+
+    def _blockwise(self, name: str, lhs: RadixCiphertext, rhs: RadixCiphertext) -> None:
+        op = getattr(self.key, f"unchecked_bit{name}_assign")
+        with self.key.deferred():
+            for a, b in zip(lhs.blocks, rhs.blocks):
+                op(a, b)
+
+    def _smart_prepare(self, lhs: RadixCiphertext, rhs: RadixCiphertext) -> None:
+        if not self.is_functional_bivariate_pbs_possible(lhs, rhs):
+            self._full_propagate_many([lhs, rhs])
+
+
+def _install_bitwise() -> None:
+    """unchecked_/checked_/smart_ bitand, bitor, bitxor (radix/bitwise_op.rs,
+    radix_parallel/bitwise_op.rs): block-wise, all blocks in one launch."""
+    for name in ("and", "or", "xor"):
+        def unchecked_assign(self, lhs, rhs, _n=name) -> None:
+            self._blockwise(_n, lhs, rhs)
+
+        def unchecked(self, lhs, rhs, _n=name):
+            res = lhs.clone()
+            self._blockwise(_n, res, rhs)
+            return res
+
+        def checked(self, lhs, rhs, _n=name):
+            if not self.is_functional_bivariate_pbs_possible(lhs, rhs):
+                raise CheckError()
+            res = lhs.clone()
+            self._blockwise(_n, res, rhs)
+            return res
+
+        def smart(self, lhs, rhs, _n=name):
+            self._smart_prepare(lhs, rhs)
+            res = lhs.clone()
+            self._blockwise(_n, res, rhs)
+            return res
+
+        def smart_assign(self, lhs, rhs, _n=name) -> None:
+            self._smart_prepare(lhs, rhs)
+            self._blockwise(_n, lhs, rhs)
+
+        setattr(ServerKey, f"unchecked_bit{name}", unchecked)
+        setattr(ServerKey, f"unchecked_bit{name}_assign", unchecked_assign)
+        setattr(ServerKey, f"checked_bit{name}", checked)
+        setattr(ServerKey, f"smart_bit{name}", smart)
+        setattr(ServerKey, f"smart_bit{name}_assign", smart_assign)
+        setattr(ServerKey, f"smart_bit{name}_parallelized", smart)
+        setattr(ServerKey, f"smart_bit{name}_assign_parallelized", smart_assign)
+
+
+_install_bitwise()

@@ -15,6 +15,7 @@ Look-up tables are cached on the device by content, where the reference rebuilds
 """
 from __future__ import annotations
 
+import contextlib
 import hashlib
 from dataclasses import dataclass
 from typing import Callable, Iterable, Sequence
@@ -23,18 +24,41 @@ import numpy as np
 
 from . import client as _client
 from .backend import CAMD_PBS_AUTO, Context, DeviceServerKey
+from .shortint_ops import CheckError, ShortintOps  # noqa: F401
 
 
 @dataclass
 class Ciphertext:
-    """LWE ciphertext under the large key, with the reference's bookkeeping fields."""
-    ct: np.ndarray            # kN+1 uint64 words, body last
+    """LWE ciphertext under the large key, with the reference's bookkeeping fields.
+
+    ``ct`` is one ciphertext (kN+1 uint64 words, body last), a host batch ([count][kN+1] numpy)
+    or a device-resident batch ([count][kN+1] torch CUDA int64 tensor); the bookkeeping fields
+    do not depend on the encrypted data and describe every ciphertext of a batch."""
+    ct: object
     degree: int
     message_modulus: int
     carry_modulus: int
 
     def clone(self) -> "Ciphertext":
-        return Ciphertext(self.ct.copy(), self.degree, self.message_modulus, self.carry_modulus)
+        data = self.ct.copy() if isinstance(self.ct, np.ndarray) else self.ct.clone()
+        return Ciphertext(data, self.degree, self.message_modulus, self.carry_modulus)
+
+    @property
+    def count(self) -> int:
+        return 1 if self.ct.ndim == 1 else int(self.ct.shape[0])
+
+    def to_device(self, device="cuda") -> "Ciphertext":
+        """Host batch -> device-resident batch (the words are reinterpreted as int64)."""
+        import torch
+
+        a = np.atleast_2d(np.ascontiguousarray(self.ct, dtype=np.uint64))
+        return Ciphertext(torch.from_numpy(a.view(np.int64)).to(device), self.degree, self.message_modulus,
+                          self.carry_modulus)
+
+    def to_host(self) -> "Ciphertext":
+        if isinstance(self.ct, np.ndarray):
+            return self.clone()
+        return Ciphertext(self.ct.cpu().numpy().view(np.uint64), self.degree, self.message_modulus, self.carry_modulus)
 
 
 class LookupTable:
@@ -96,8 +120,17 @@ class ClientKey:
         rounding = (int(phase) & (delta >> 1)) << 1
         return ((int(phase) + rounding) & 0xFFFFFFFFFFFFFFFF) // delta
 
-    def decrypt_message_and_carry(self, ct: Ciphertext) -> int:
-        return self.decode(_client.lwe_phase(64, self.lwe_secret_key, ct.ct)[0])
+    def decrypt_message_and_carry(self, ct: Ciphertext):
+        """One ciphertext -> int; a batch (host or device) -> int64 array."""
+        data = ct.ct if isinstance(ct.ct, np.ndarray) else ct.ct.cpu().numpy().view(np.uint64)
+        if data.ndim == 1:
+            return self.decode(_client.lwe_phase(64, self.lwe_secret_key, data)[0])
+        return self.decrypt_message_and_carry_batch(np.ascontiguousarray(data))
+
+    def encrypt_many(self, messages: Iterable[int]) -> Ciphertext:
+        """A host batch of fresh encryptions sharing one set of bookkeeping fields."""
+        p = self.parameters
+        return Ciphertext(self.encrypt_batch(messages), p.message_modulus - 1, p.message_modulus, p.carry_modulus)
 
     def decrypt(self, ct: Ciphertext) -> int:
         return self.decrypt_message_and_carry(ct) % ct.message_modulus
@@ -107,8 +140,9 @@ class ClientKey:
         return np.array([self.decode(int(ph)) for ph in phases], dtype=np.int64)
 
 
-class ServerKey:
-    """GPU-resident server key: keyswitch key + Fourier bootstrap key + moduli.
+class ServerKey(ShortintOps):
+    """GPU-resident server key: keyswitch key + Fourier bootstrap key + moduli. The operation
+    layer (add, mul, comparisons, ...) comes from ``ShortintOps``.
 
     ``ServerKey.new(cks)`` follows engine/server_side/mod.rs:22-72: the bootstrap key is generated
     in the standard domain, converted to the Fourier domain (here: on the GPU), and dropped.
@@ -121,6 +155,8 @@ class ServerKey:
         self.carry_modulus = parameters.carry_modulus
         self.max_degree = (parameters.message_modulus * parameters.carry_modulus - 1) if max_degree is None else max_degree
         self._lut_cache: dict[bytes, LookupTable] = {}
+        self._device_ids: dict = {}   # (lut id, count) -> device array of ids, reused across calls
+        self._queue = None            # bootstraps collected by deferred()
         # engine/mod.rs:195-199: the default accumulator is x -> x % message_modulus
         msg = self.message_modulus
         self._default_acc = self.generate_accumulator(lambda x: x % msg)
@@ -158,9 +194,44 @@ class ServerKey:
         self.keyswitch_programmable_bootstrap_assign(res, acc)
         return res
 
+    @contextlib.contextmanager
+    def deferred(self):
+        """Collect the bootstraps issued inside the ``with`` block and run them as ONE launch when
+        it ends. Valid whenever the operations inside are independent of each other's results
+        (degrees and moduli are data-independent bookkeeping and are updated immediately): what
+        the reference hands to rayon workers (concrete-integer radix_parallel/mul.rs:55-72,
+        bitwise_op.rs) becomes a single batch here. Nested uses flush at the outermost level."""
+        if self._queue is not None:
+            yield
+            return
+        self._queue = []
+        try:
+            yield
+        finally:
+            items, self._queue = self._queue, None
+        self.apply_lookup_table_many(items)
+
     def keyswitch_programmable_bootstrap_assign(self, ct: Ciphertext, acc: LookupTable) -> None:
         """server_key/mod.rs:219-229 -> engine/server_side/mod.rs:131-155. Degree is not touched."""
-        ct.ct = self.key.ks_pbs(ct.ct[None, :], np.array([acc.lut_id], dtype=np.uint32))[0]
+        if self._queue is not None:
+            self._queue.append((ct, acc))
+            return
+        if isinstance(ct.ct, np.ndarray):
+            if ct.ct.ndim == 1:
+                ct.ct = self.key.ks_pbs(ct.ct[None, :], np.array([acc.lut_id], dtype=np.uint32))[0]
+            else:
+                ct.ct = self.key.ks_pbs(ct.ct, np.full(ct.ct.shape[0], acc.lut_id, dtype=np.uint32))
+            return
+        import torch
+
+        count = ct.ct.shape[0]
+        ids = self._device_ids.get((acc.lut_id, count))
+        if ids is None:
+            ids = torch.full((count,), acc.lut_id, dtype=torch.int32, device=ct.ct.device)
+            self._device_ids[(acc.lut_id, count)] = ids
+        out = torch.empty_like(ct.ct)
+        self.key.ks_pbs_device(ct.ct, ids, out, count, torch.cuda.current_stream().cuda_stream)
+        ct.ct = out
 
     def keyswitch_bootstrap(self, ct: Ciphertext) -> Ciphertext:
         """server_key/mod.rs:172-175 -> engine/server_side/mod.rs:85-118 (default accumulator)."""
@@ -193,34 +264,25 @@ class ServerKey:
         self.message_extract_assign(res)
         return res
 
-    def create_trivial(self, value: int) -> Ciphertext:
-        """engine/server_side/mod.rs:250-282: mask zero, sized with the bootstrap output dimension."""
+    def create_trivial(self, value: int, like: Ciphertext | None = None) -> Ciphertext:
+        """engine/server_side/mod.rs:250-282: mask zero, sized with the bootstrap output dimension.
+        With ``like`` the result is a batch of the same size and residency as ``like``."""
         p = self.parameters
         modular_value = int(value) % self.message_modulus
         delta = (1 << 63) // (self.message_modulus * self.carry_modulus)
-        ct = np.zeros(p.glwe_dimension * p.polynomial_size + 1, dtype=np.uint64)
-        ct[-1] = np.uint64(modular_value * delta)
+        words = p.glwe_dimension * p.polynomial_size + 1
+        if like is None or (isinstance(like.ct, np.ndarray) and like.ct.ndim == 1):
+            ct = np.zeros(words, dtype=np.uint64)
+            ct[-1] = np.uint64(modular_value * delta)
+        elif isinstance(like.ct, np.ndarray):
+            ct = np.zeros((like.ct.shape[0], words), dtype=np.uint64)
+            ct[:, -1] = np.uint64(modular_value * delta)
+        else:
+            import torch
+
+            ct = torch.zeros((like.ct.shape[0], words), dtype=torch.int64, device=like.ct.device)
+            ct[:, -1] = modular_value * delta
         return Ciphertext(ct, modular_value, self.message_modulus, self.carry_modulus)
-
-    # ---- leveled operations that feed the path (engine/server_side/{add,scalar_mul}.rs) ----
-    def unchecked_add_assign(self, lhs: Ciphertext, rhs: Ciphertext) -> None:
-        """engine/server_side/add.rs:17-26: wrapping add of the LWE words, degrees add."""
-        lhs.ct = lhs.ct + rhs.ct
-        lhs.degree += rhs.degree
-
-    def unchecked_scalar_mul_assign(self, ct: Ciphertext, scalar: int) -> None:
-        """engine/server_side/scalar_mul.rs:19-30."""
-        ct.ct = ct.ct * np.uint64(int(scalar) & 0xFF)
-        ct.degree *= int(scalar)
-
-    def unchecked_functional_bivariate_pbs(self, lhs: Ciphertext, rhs: Ciphertext, f: Callable[[int], int]) -> Ciphertext:
-        """engine/server_side/mod.rs:157-196: lhs*(deg_r+1) + rhs, then one bootstrap with f."""
-        res = lhs.clone()
-        modulus = rhs.degree + 1
-        self.unchecked_scalar_mul_assign(res, modulus)
-        self.unchecked_add_assign(res, rhs)
-        self.keyswitch_programmable_bootstrap_assign(res, self.generate_accumulator(f))
-        return res
 
     # ---- batched forms ----
     def keyswitch_programmable_bootstrap_batch(self, cts: np.ndarray, accs: Sequence[LookupTable] | LookupTable) -> np.ndarray:

@@ -136,6 +136,22 @@ int camd_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_
 int camd_ks_batch_device(camd_server_key* key, const void* ct_in, void* ct_out, size_t count,
                          void* stream);
 
+/* ---- leveled operations on device ciphertexts (asynchronous on `stream`) ----
+ * out[c][j] = alpha * x[c][j] + beta * y[c][j] (wrapping, j < words), then body_add is added to the
+ * last word of every row; y may be NULL (then beta is ignored). Rows c < count start
+ * `*_stride` words apart, so blocks of a batch of radix integers can be addressed in place; out
+ * may alias x or y. Replaces the concrete-core calls the reference makes around a bootstrap:
+ * fuse_add_lwe_ciphertext (concrete-shortint/src/engine/server_side/add.rs:22),
+ * fuse_opp_lwe_ciphertext + fuse_add_lwe_ciphertext_plaintext (neg.rs:59-66),
+ * fuse_mul_lwe_ciphertext_cleartext (scalar_mul.rs:26-27), the shift-and-add ahead of a
+ * bivariate bootstrap (mod.rs:182-188) and the boolean gate combinations
+ * (concrete-boolean/src/engine/mod.rs:347-353). alpha, beta, body_add are truncated to
+ * torus_bits. */
+int camd_lwe_axpby_device(camd_context* ctx, uint32_t torus_bits, void* out, size_t out_stride,
+                          const void* x, size_t x_stride, uint64_t alpha, const void* y,
+                          size_t y_stride, uint64_t beta, uint64_t body_add, size_t words,
+                          size_t count, void* stream);
+
 /* ---- measurement helpers ----
  * Average device time in milliseconds of the bootstrap kernel (and of the keyswitch kernel)
  * over the launches made since the last reset, taken with HIP events on the stream the
