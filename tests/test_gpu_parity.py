@@ -106,3 +106,76 @@ def test_ks_pbs_parity_2_2(gpu_ctx, keys_2_2, variant):
     err_g, err_w = np.array(err_g), np.array(err_w)
     assert np.abs(err_g).max() < PHASE_TOL
     assert err_g.var() < VARIANCE_RATIO * err_w.var() + 1e-30
+
+
+def gadget_variance(p):
+    """Predicted output variance of one bootstrap in torus^2 units from the gadget decomposition
+    (Chillotti-Ligier-Orfila-Tap 2021, binary keys): key noise amplified by the digits, plus the
+    rounding of the decomposition; the two 1/q^2 terms of the formula are below 1e-30 and dropped."""
+    n, k, N, L = p.lwe_dimension, p.glwe_dimension, p.polynomial_size, p.pbs_level
+    B = 2.0 ** p.pbs_base_log
+    key_term = n * L * (k + 1) * N * ((B * B + 2.0) / 12.0) * p.glwe_modular_std_dev ** 2
+    rounding_term = n * (1.0 / (24.0 * B ** (2 * L))) * (1.0 + k * N / 2.0)
+    return key_term + rounding_term
+
+
+def fft_variance(p, o):
+    """Variance the f64 transforms add to the output phase. One digit-polynomial x key-polynomial
+    product carries a rounding error e per coefficient (measured here against the exact integer
+    product, about 2^-26 of the torus for 2^22-sized digits at N = 1024); a CMUX sums (k+1)L such
+    products per output polynomial, and decryption multiplies the mask errors by the binary secret
+    key, so each CMUX - whatever its key bit - adds (k+1)L (1 + kN/2) var(e) to the phase."""
+    n, k, N, L = p.lwe_dimension, p.glwe_dimension, p.polynomial_size, p.pbs_level
+    half = 1 << (p.pbs_base_log - 1)
+    rs = np.random.RandomState(5)
+    M = N // 2
+    errs = []
+    for _ in range(4):
+        a = rs.randint(0, 2 ** 63, N, dtype=np.uint64) * np.uint64(2) + rs.randint(0, 2, N).astype(np.uint64)
+        b = rs.randint(-half, half, N).astype(np.int64)
+        fa, fb = o.fft_forward_torus(a), o.fft_forward_integer(b.astype(np.uint64))
+        prod = np.concatenate([fa[:M] * fb[:M] - fa[M:] * fb[M:], fa[:M] * fb[M:] + fa[M:] * fb[:M]])
+        got = o.fft_add_backward_torus(prod, np.zeros(N, dtype=np.uint64))
+        errs.append((got - O.negacyclic_schoolbook(a, b)).view(np.int64).astype(np.float64) / 2.0 ** 64)
+    return n * (k + 1) * L * (1.0 + k * N / 2.0) * np.concatenate(errs).var()
+
+
+def test_output_noise_variance_2_2(gpu_ctx, keys_2_2):
+    """Acceptance bar for the fast kernel: over 2^14 bootstraps the variance of the output phase
+    error stays within the predicted figure (gadget noise + the f64 transforms' rounding, the
+    tolerance the path is allowed) and does not exceed the oracle's (measured on a 4096-ciphertext
+    subset) beyond sampling error; decryptions agree ciphertext by ciphertext."""
+    ks = keys_2_2
+    p = ks.params
+    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    lut = ks.o.generate_accumulator(lambda x: x % 4)
+    dk.upload_lut(lut)
+    from concrete_amd import client as CL
+
+    rng = CL.Rng(99)
+    count, sub = 1 << 14, 1 << 12
+    delta = O.shortint_delta(p)
+    msgs = np.arange(count) % 4
+    cts = CL.lwe_encrypt(rng, 64, ks.glwe, [int(m) * delta for m in msgs], ks.lwe_std)
+    got = dk.ks_pbs(cts)
+    want = ks.o.ks_pbs_batch(ks.ksk, ks.fbsk, lut, None, cts[:sub], threads=16)
+
+    def phase_error(out):
+        ph = CL.lwe_phase(64, ks.glwe, out).astype(np.uint64)
+        nearest = ((ph + np.uint64(delta // 2)) // np.uint64(delta)) * np.uint64(delta)   # wraps like the torus
+        return (ph - nearest).view(np.int64).astype(np.float64) / 2.0 ** 64, (nearest // np.uint64(delta)) % np.uint64(16)
+
+    err_g, dec_g = phase_error(got)
+    err_w, dec_w = phase_error(want)
+    # identical decryption wherever the oracle was run; wrong boxes only at the parameter set's own rate
+    assert np.array_equal(dec_g[:sub], dec_w)
+    assert np.count_nonzero(dec_g != msgs.astype(np.uint64)) <= 8       # expectation 2^14 * 2^-13.9 = 1.1
+    gadget, fft = gadget_variance(p), fft_variance(p, ks.o)
+    bound = gadget + fft
+    print(f"variance: gpu {err_g.var():.4e} (subset {err_g[:sub].var():.4e}), oracle {err_w.var():.4e}, "
+          f"predicted {bound:.4e} = gadget {gadget:.4e} + f64 transforms {fft:.4e}")
+    assert gadget < err_g.var() < 1.2 * bound, (err_g.var(), bound)
+    assert gadget < err_w.var() < 1.2 * bound
+    ratio = err_g[:sub].var() / err_w.var()
+    assert 0.75 < ratio < 1.15, ratio       # radix-8 transforms round less often than the oracle's radix-2
+    assert abs(err_g.mean()) < 4 * np.sqrt(bound / count)               # no bias from the fast rounding
