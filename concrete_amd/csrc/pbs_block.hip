@@ -38,6 +38,17 @@ namespace {
 
 constexpr uint32_t SWZ_BITS = 4;  // a 16-lane group of ds_read_b128 must touch 16 distinct 16-byte units
 
+// Global accesses as (wave-uniform base, 32-bit byte offset): the hardware adds the scalar base
+// itself, so no 64-bit address registers are built or kept alive per access.
+template <typename V>
+__device__ __forceinline__ V gld(const void* base, uint32_t byte_off) {
+  return *(const V*)((const char*)base + byte_off);
+}
+template <typename V>
+__device__ __forceinline__ void gst(void* base, uint32_t byte_off, V v) {
+  *(V*)((char*)base + byte_off) = v;
+}
+
 template <int PL>
 struct Blk {
   static constexpr int P = 1 << PL;
@@ -55,7 +66,7 @@ struct Blk {
 // twiddle of stage bit b, butterfly index j (< 2^b): W_{2^(b+1)}^j
 __device__ __forceinline__ double2 stage_twiddle(bool from_global, const double2* __restrict__ gtw, const double2* ltw,
                                                  uint32_t b, uint32_t j, uint32_t B) {
-  if (from_global) return gtw[(size_t)j << (B - 1u - b)];
+  if (from_global) return gld<double2>(gtw, (j << (B - 1u - b)) * (uint32_t)sizeof(double2));
   return ltw[((1u << b) - 1u) + j];
 }
 
@@ -129,8 +140,15 @@ __device__ __forceinline__ void exchange(double2 (&x)[1 << PL], double2* buf, ui
 constexpr int block_waves(int PL, int KP1) {
   const int need = KP1 * (1 << PL) * 4 + (1 << PL) * 4 + 40;
   const int w = 512 / need;
-  if (PL >= 4) return 2;  // 512-thread workgroups, one per CU: nothing to gain from fewer registers
+  if (PL >= 3) return 2;  // room to keep a whole phase's loads in flight beats a third wave per SIMD
   return w > 4 ? 4 : (w < 1 ? 1 : w);
+}
+
+// largest power of two <= want, within [1, P]
+constexpr int group_points(int want, int P) {
+  int g = 1;
+  while (2 * g <= want && 2 * g <= P) g *= 2;
+  return g;
 }
 
 constexpr int pass_lo(int B, int PL, int q) { return B - (q + 1) * PL > 0 ? B - (q + 1) * PL : 0; }
@@ -226,7 +244,14 @@ void block_pbs_kernel(PbsLaunch<T> a) {
   constexpr int CREG = block_reg_columns(B, KP1);
   // points handled between two scheduling fences in the load-heavy phases: bounds the registers
   // the compiler may spend on loads in flight
-  constexpr int GROUP = 4;
+  // points per load group of each phase: what fits the registers left next to the Fourier sums
+  // and the polynomial slice (a point costs 12 registers in the gather, 6 when the parked states
+  // are read back, 4 or 8 in the multiply-accumulate, 8 in the update)
+  constexpr int FREE = 512 / block_waves(PL, CREG) - (CREG * P * 4 + P * 4) - (PL >= 4 ? 64 : 40);
+  constexpr int GG = group_points(FREE / 12, P);
+  constexpr int GS = group_points(FREE / 6, P);
+  constexpr int GM = group_points(FREE / (KP1 > CREG ? 8 : 4), P);
+  constexpr int GU = group_points((FREE + (CREG < KP1 ? 0 : 0)) / 8, P);
   double2* buf = lds;
   double2* ltw = lds + M;
   const double2* twist = a.tables;
@@ -255,9 +280,18 @@ void block_pbs_kernel(PbsLaunch<T> a) {
     }
     __syncthreads();
 
+#ifdef BLOCK_PROFILE
+    uint64_t tG = 0, tF = 0, tM = 0, tI = 0, tU = 0, t0, t1;
+#define STAMP(acc) t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1;
+#else
+#define STAMP(acc)
+#endif
     for (uint32_t i = 0; i < n; i++) {
       const T ai = in[i];
       if (ai == 0) continue;  // uniform over the workgroup
+#ifdef BLOCK_PROFILE
+      t0 = __builtin_amdgcn_s_memtime();
+#endif
       const uint32_t a_hat = modswitch<T>(ai, logN) & (2 * N - 1);
       double2 accf[CREG][P];
 #pragma unroll 1
@@ -271,70 +305,117 @@ void block_pbs_kernel(PbsLaunch<T> a) {
           const T* p = ct0 + (size_t)r * N;
           uint32_t* str = st + (size_t)r * N;
           double2 x[P];
+          // Every load-heavy phase is written as: issue all loads of a group, a scheduling fence,
+          // then the arithmetic. Left alone the compiler serialises load / wait / use per point
+          // when registers are tight, and each wait is a full trip to L2 or HBM.
           if (l == L) {
             // rotated difference of row r, first (finest) digit; the rest of the state is parked
 #pragma unroll
-            for (int q = 0; q < P; q++) {
-              const uint32_t j = (uint32_t)q * Tn + t;
-              const T x0 = rotated_coeff<T>(p, j, a_rot, N) - p[j];
-              const T x1 = rotated_coeff<T>(p, j + M, a_rot, N) - p[j + M];
-              T s0 = decomp_init_state<T>(x0, bl, L);
-              T s1 = decomp_init_state<T>(x1, bl, L);
-              const S g0 = decomp_next<T>(s0, bl);
-              const S g1 = decomp_next<T>(s1, bl);
-              if constexpr (L > 1) {
-                str[(uint32_t)(2 * q) * Tn + t] = (uint32_t)s0;
-                str[(uint32_t)(2 * q + 1) * Tn + t] = (uint32_t)s1;
+            for (int q0 = 0; q0 < P; q0 += GG) {
+              T rot0[GG], rot1[GG], own0[GG], own1[GG];
+              double2 tw[GG];
+#pragma unroll
+              for (int u = 0; u < GG; u++) {
+                const uint32_t j = (uint32_t)(q0 + u) * Tn + t;
+                const uint32_t s0 = (j - a_rot) & (2 * N - 1), s1 = (j + M - a_rot) & (2 * N - 1);
+                rot0[u] = gld<T>(p, (s0 & (N - 1)) * (uint32_t)sizeof(T));
+                rot1[u] = gld<T>(p, (s1 & (N - 1)) * (uint32_t)sizeof(T));
+                own0[u] = gld<T>(p, j * (uint32_t)sizeof(T));
+                own1[u] = gld<T>(p, (j + M) * (uint32_t)sizeof(T));
+                tw[u] = gld<double2>(twist, j * (uint32_t)sizeof(double2));
               }
-              x[q] = cmul(make_double2(signed_to_double(g0), signed_to_double(g1)), twist[j]);
-              if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < GG; u++) {
+                const int q = q0 + u;
+                const uint32_t j = (uint32_t)q * Tn + t;
+                const uint32_t s0 = (j - a_rot) & (2 * N - 1), s1 = (j + M - a_rot) & (2 * N - 1);
+                const T x0 = ((s0 & N) ? (T)(T(0) - rot0[u]) : rot0[u]) - own0[u];
+                const T x1 = ((s1 & N) ? (T)(T(0) - rot1[u]) : rot1[u]) - own1[u];
+                T st0 = decomp_init_state<T>(x0, bl, L);
+                T st1 = decomp_init_state<T>(x1, bl, L);
+                const S g0 = decomp_next<T>(st0, bl);
+                const S g1 = decomp_next<T>(st1, bl);
+                if constexpr (L > 1) {
+                  gst<uint32_t>(str, ((uint32_t)(2 * q) * Tn + t) * 4u, (uint32_t)st0);
+                  gst<uint32_t>(str, ((uint32_t)(2 * q + 1) * Tn + t) * 4u, (uint32_t)st1);
+                }
+                x[q] = cmul(make_double2(signed_to_double(g0), signed_to_double(g1)), tw[u]);
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
           } else {
 #pragma unroll
-            for (int q = 0; q < P; q++) {
-              const uint32_t j = (uint32_t)q * Tn + t;
-              T s0 = (T)str[(uint32_t)(2 * q) * Tn + t];
-              T s1 = (T)str[(uint32_t)(2 * q + 1) * Tn + t];
-              const S g0 = decomp_next<T>(s0, bl);
-              const S g1 = decomp_next<T>(s1, bl);
-              if constexpr (L > 2) {  // with two levels the state is spent after this digit
-                str[(uint32_t)(2 * q) * Tn + t] = (uint32_t)s0;
-                str[(uint32_t)(2 * q + 1) * Tn + t] = (uint32_t)s1;
+            for (int q0 = 0; q0 < P; q0 += GS) {
+              uint32_t sa[GS], sb[GS];
+              double2 tw[GS];
+#pragma unroll
+              for (int u = 0; u < GS; u++) {
+                sa[u] = gld<uint32_t>(str, ((uint32_t)(2 * (q0 + u)) * Tn + t) * 4u);
+                sb[u] = gld<uint32_t>(str, ((uint32_t)(2 * (q0 + u) + 1) * Tn + t) * 4u);
+                tw[u] = gld<double2>(twist, ((uint32_t)(q0 + u) * Tn + t) * (uint32_t)sizeof(double2));
               }
-              x[q] = cmul(make_double2(signed_to_double(g0), signed_to_double(g1)), twist[j]);
-              if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < GS; u++) {
+                const int q = q0 + u;
+                T st0 = (T)sa[u], st1 = (T)sb[u];
+                const S g0 = decomp_next<T>(st0, bl);
+                const S g1 = decomp_next<T>(st1, bl);
+                if constexpr (L > 2) {  // with two levels the state is spent after this digit
+                  gst<uint32_t>(str, ((uint32_t)(2 * q) * Tn + t) * 4u, (uint32_t)st0);
+                  gst<uint32_t>(str, ((uint32_t)(2 * q + 1) * Tn + t) * 4u, (uint32_t)st1);
+                }
+                x[q] = cmul(make_double2(signed_to_double(g0), signed_to_double(g1)), tw[u]);
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
-          block_fft_forward<B, PL>(x, buf, ltw, gtw, t);
-          asm volatile("" : "+v"(t));
+          STAMP(tG)
           const double2* rows = a.fbsk + ((((size_t)i * L + (l - 1)) * KP1 + r) * KP1) * M;
+          block_fft_forward<B, PL>(x, buf, ltw, gtw, t);
+          STAMP(tF)
+          asm volatile("" : "+v"(t));
           if (l == L && r == 0) {
 #pragma unroll
             for (int c = 0; c < KP1; c++) {
 #pragma unroll
-              for (int q = 0; q < P; q++) {
-                const double2 v = cmul(rows[(size_t)c * M + (uint32_t)q * Tn + t], x[q]);
-                if (c < CREG) accf[c < CREG ? c : 0][q] = v;
-                else accg[(size_t)(c - CREG) * M + (uint32_t)q * Tn + t] = v;
-                if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+              for (int q0 = 0; q0 < P; q0 += GM) {
+                double2 w[GM];
+#pragma unroll
+                for (int u = 0; u < GM; u++) w[u] = gld<double2>(rows, ((uint32_t)c * M + (uint32_t)(q0 + u) * Tn + t) * 16u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < GM; u++) {
+                  const double2 v = cmul(w[u], x[q0 + u]);
+                  if (c < CREG) accf[c < CREG ? c : 0][q0 + u] = v;
+                  else gst<double2>(accg, ((uint32_t)(c - CREG) * M + (uint32_t)(q0 + u) * Tn + t) * 16u, v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
               }
             }
           } else {
 #pragma unroll
             for (int c = 0; c < KP1; c++) {
 #pragma unroll
-              for (int q = 0; q < P; q++) {
-                const double2 w = rows[(size_t)c * M + (uint32_t)q * Tn + t];
-                if (c < CREG) {
-                  accf[c < CREG ? c : 0][q] = cfma(w, x[q], accf[c < CREG ? c : 0][q]);
-                } else {
-                  double2* slot = accg + (size_t)(c - CREG) * M + (uint32_t)q * Tn + t;
-                  *slot = cfma(w, x[q], *slot);
+              for (int q0 = 0; q0 < P; q0 += GM) {
+                double2 w[GM], old[GM];
+#pragma unroll
+                for (int u = 0; u < GM; u++) {
+                  w[u] = gld<double2>(rows, ((uint32_t)c * M + (uint32_t)(q0 + u) * Tn + t) * 16u);
+                  if (c >= CREG) old[u] = gld<double2>(accg, ((uint32_t)(c - CREG) * M + (uint32_t)(q0 + u) * Tn + t) * 16u);
                 }
-                if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < GM; u++) {
+                  if (c < CREG) accf[c < CREG ? c : 0][q0 + u] = cfma(w[u], x[q0 + u], accf[c < CREG ? c : 0][q0 + u]);
+                  else gst<double2>(accg, ((uint32_t)(c - CREG) * M + (uint32_t)(q0 + u) * Tn + t) * 16u, cfma(w[u], x[q0 + u], old[u]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
               }
             }
           }
+          STAMP(tM)
         }
       }
       // every gather of this CMUX is done (each thread reads coefficients other threads update)
@@ -345,21 +426,42 @@ void block_pbs_kernel(PbsLaunch<T> a) {
         asm volatile("" : "+v"(t));
 #pragma unroll
         for (int q = 0; q < P; q++)
-          x[q] = (c < CREG) ? accf[c < CREG ? c : 0][q] : accg[(size_t)(c - CREG) * M + (uint32_t)q * Tn + t];
+          x[q] = (c < CREG) ? accf[c < CREG ? c : 0][q] : gld<double2>(accg, ((uint32_t)(c - CREG) * M + (uint32_t)q * Tn + t) * 16u);
+        STAMP(tM)
         block_fft_inverse<B, PL>(x, buf, ltw, gtw, t);
+        STAMP(tI)
         asm volatile("" : "+v"(t));
         T* p = ct0 + (size_t)c * N;
 #pragma unroll
-        for (int q = 0; q < P; q++) {
-          const uint32_t j = (uint32_t)q * Tn + t;
-          const double2 v = cmul_conj(x[q], twist[j]);
-          p[j] += from_torus_faithful<T>(v.x * inv_m);
-          p[j + M] += from_torus_faithful<T>(v.y * inv_m);
-          if ((q & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        for (int q0 = 0; q0 < P; q0 += GU) {
+          T lo[GU], hi[GU];
+          double2 tw[GU];
+#pragma unroll
+          for (int u = 0; u < GU; u++) {
+            const uint32_t j = (uint32_t)(q0 + u) * Tn + t;
+            lo[u] = gld<T>(p, j * (uint32_t)sizeof(T));
+            hi[u] = gld<T>(p, (j + M) * (uint32_t)sizeof(T));
+            tw[u] = gld<double2>(twist, j * (uint32_t)sizeof(double2));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < GU; u++) {
+            const uint32_t j = (uint32_t)(q0 + u) * Tn + t;
+            const double2 v = cmul_conj(x[q0 + u], tw[u]);
+            gst<T>(p, j * (uint32_t)sizeof(T), lo[u] + from_torus_faithful<T>(v.x * inv_m));
+            gst<T>(p, (j + M) * (uint32_t)sizeof(T), hi[u] + from_torus_faithful<T>(v.y * inv_m));
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __syncthreads();
+      STAMP(tU)
     }
+#ifdef BLOCK_PROFILE
+    if ((ct == 0 || ct == 100) && tid == 0)
+      printf("ct %lu ticks per CMUX: gather %lu fwd %lu mac %lu inv %lu update %lu\n", (unsigned long)ct, (unsigned long)(tG / n),
+             (unsigned long)(tF / n), (unsigned long)(tM / n), (unsigned long)(tI / n), (unsigned long)(tU / n));
+#endif
 
     // sample extraction of coefficient 0
     T* out = a.ct_out + ct * a.out_stride;
