@@ -223,6 +223,8 @@ int reserve_locked(camd_server_key* key, size_t count) {
   } else if (key->variant == CAMD_PBS_BLOCK) {
     unsigned grid = 1;
     rc = key->pbs_scratch.ensure(block_scratch_bytes(p, &grid, count));
+  } else if (key->variant == CAMD_PBS_WAVE) {
+    rc = key->pbs_scratch.ensure(wave_scratch_bytes());
   }
   return rc;
 }

@@ -20,7 +20,7 @@ struct PbsLaunch {
   size_t count;
   const double2* fbsk;       // Fourier bootstrap key in the layout of the kernel family
   const double2* tables;     // twiddle tables of the kernel family
-  void* scratch;             // per-workgroup scratch (generic and block families)
+  void* scratch;             // per-workgroup scratch (generic and block families), arrival counters (wave family)
   uint32_t n, k, N, level, base_log;
 };
 
@@ -59,6 +59,7 @@ int block_launch_pbs(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream);
 // ---- wave-per-polynomial bootstrap for N in {512, 1024, 2048} (pbs_wave.hip) ----
 bool wave_supported(const camd_params& p);
 size_t wave_tables_count(uint32_t N);
+size_t wave_scratch_bytes();   // arrival counters of the persistent waves, cleared by every launch
 void wave_fill_tables(uint32_t N, double2* host_tables);
 template <typename T>
 int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, const camd_params& p,

@@ -577,6 +577,11 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
 // Per CMUX: gather the k+1 rotated differences, run the k+1 forward transforms interleaved,
 // multiply-accumulate against the whole GGSW (held in registers, loaded during the previous
 // iteration's inverse transforms), run the k+1 inverse transforms interleaved, round and add.
+// a wave moves on once all but 1/8 of its XCD's waves have arrived: waiting for the very last
+// straggler costs 1.5 % of the run, this costs nothing and keeps the fetch traffic at its minimum
+constexpr uint32_t WAVE_QUORUM_SLACK = 8;
+constexpr int SYNC_GROUPS = 8;          // one arrival counter per XCD
+constexpr int SYNC_STRIDE = 32;         // counters 128 bytes apart
 template <typename T, int K, int BL>
 __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1;
@@ -587,14 +592,26 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const size_t ct = (size_t)blockIdx.x * WAVES + wave;
-  if (ct >= a.count) return;
-
   char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
   T* ct0 = (T*)slab;
   double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
   double* sim = sre + PLANE;
 
+  // Persistent waves: the grid is sized to the device (one workgroup per CU) and every wave
+  // walks its ciphertexts with a grid stride. All waves then start each of their ciphertexts at
+  // about the same time, so the waves of an XCD read a key row within the same short window and
+  // it is fetched into that XCD's L2 once; with one workgroup per four ciphertexts the start
+  // times spread out as the launch progresses and every row was fetched about five times.
+  // Waves that share an L2 (workgroups are dealt round-robin to the 8 XCDs) restart together:
+  // after each ciphertext a wave reports to its XCD's counter and waits until all of them have.
+  // Without this the waves drift apart by more key rows than the 4 MB L2 holds within a few
+  // ciphertexts, and each row is fetched from the fabric many times per XCD.
+  const uint32_t group = blockIdx.x % SYNC_GROUPS;
+  const uint32_t group_waves = ((gridDim.x - group + SYNC_GROUPS - 1) / SYNC_GROUPS) * WAVES;
+  uint32_t* arrivals = (uint32_t*)a.scratch + group * SYNC_STRIDE;
+  const size_t per_round = (size_t)gridDim.x * WAVES;
+  uint32_t round = 0;
+  for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round, round++) {
   const T* in = a.ct_in + ct * a.in_stride;
   const uint32_t n = a.n;
   const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
@@ -826,6 +843,21 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
     out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
   }
   if (lane == 0) out[K * N] = ct0[K * N];
+  // rendezvous, only when a further round follows (this one was then a full round); the
+  // wait is bounded so that a wave can never be held forever (the order of work does not
+  // affect results, only cache behaviour)
+  if ((size_t)(round + 1) * per_round < a.count) {
+    if (lane == 0) {
+      __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t target = (round + 1) * group_waves - group_waves / WAVE_QUORUM_SLACK;
+      for (uint32_t spin = 0; spin < (1u << 16); spin++) {
+        if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  }
 }
 
 template <typename T, int K, int L, int BL>
@@ -841,7 +873,15 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     if (schedule == 2) {
       auto kern2 = wave_pbs_kernel_v2<T, K, BL>;
       CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern2, dim3(grid), dim3(256), lds, stream, a);
+      int dev = 0, cus = 0;
+      CAMD_HIP(hipGetDevice(&dev));
+      CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // LDS allows one workgroup per CU
+      if (persistent < grid) {
+        if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
+        CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
+      }
+      hipLaunchKernelGGL(kern2, dim3(persistent), dim3(256), lds, stream, a);
       CAMD_HIP(hipGetLastError());
       return CAMD_OK;
     }
@@ -854,6 +894,8 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+size_t wave_scratch_bytes() { return (size_t)SYNC_GROUPS * SYNC_STRIDE * sizeof(uint32_t); }
 
 bool wave_supported(const camd_params& p) {
   if (p.polynomial_size != 1024) return false;
