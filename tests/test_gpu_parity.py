@@ -179,3 +179,29 @@ def test_output_noise_variance_2_2(gpu_ctx, keys_2_2):
     ratio = err_g[:sub].var() / err_w.var()
     assert 0.75 < ratio < 1.15, ratio       # radix-8 transforms round less often than the oracle's radix-2
     assert abs(err_g.mean()) < 4 * np.sqrt(bound / count)               # no bias from the fast rounding
+
+
+def test_wave_persistent_rounds_and_tail(gpu_ctx, keys_2_2):
+    """More ciphertexts than resident waves, not a multiple of anything: every wave runs two
+    rounds with a rendezvous in between, a few run a third, partial one. Same decryptions as the
+    oracle for each ciphertext, whatever its position."""
+    import torch
+
+    ks = keys_2_2
+    p = ks.params
+    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    lut = ks.o.generate_accumulator(lambda x: (3 * x) % 4)
+    dk.upload_lut(lut)
+    from concrete_amd import client as CL
+
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    count = 2 * 4 * cus + 7
+    rng = CL.Rng(4242)
+    delta = O.shortint_delta(p)
+    msgs = np.arange(count) % 16
+    cts = CL.lwe_encrypt(rng, 64, ks.glwe, [int(m) * delta for m in msgs], ks.lwe_std)
+    got = dk.ks_pbs(cts)
+    want = ks.o.ks_pbs_batch(ks.ksk, ks.fbsk, lut, None, cts, threads=16)
+    dec = lambda out: np.array([O.shortint_decode(p, int(ph)) for ph in CL.lwe_phase(64, ks.glwe, out)])
+    assert np.array_equal(dec(got), dec(want))
+    assert np.count_nonzero(dec(got) != (3 * msgs) % 4) <= 3   # the parameter set's own failure rate
