@@ -103,6 +103,99 @@ def cpu_baseline(p, bsk, ksk, lut, cts_host, cores: int):
                       f"{dt:.2f} s wall"}, res
 
 
+OTHER_WORKLOADS = {
+    # name: (parameter set, default batch per GPU, torus bits, order)
+    "4_4": ("PARAM_MESSAGE_4_CARRY_4", 512, 64, "ks_pbs"),
+    "3_3": ("PARAM_MESSAGE_3_CARRY_3", 4096, 64, "ks_pbs"),
+    "boolean": ("DEFAULT_PARAMETERS", 1 << 15, 32, "pbs_ks"),
+}
+
+
+def other_workload(args) -> None:
+    """Further configurations (largest polynomial size, boolean gates): same contract, random key
+    material and random ciphertexts, so there is no decryption check and no CPU baseline."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    pname, default_batch, bits, order = OTHER_WORKLOADS[args.workload]
+    p = getattr(P, pname)
+    count = args.batch if args.batch != 1 << 14 else default_batch
+    n, k, N, L = p.lwe_dimension, p.glwe_dimension, p.polynomial_size, p.pbs_level
+    dt = np.uint64 if bits == 64 else np.uint32
+    rs = np.random.RandomState(SEED & 0xFFFF)
+
+    def rnd(shape):
+        return rs.randint(0, 2 ** 31, size=shape, dtype=np.int64).astype(dt) * dt(2)
+
+    ctx = Context(local_rank)
+    dk = None
+    if rank == 0:
+        dk = DeviceServerKey.from_standard_keys(ctx, p, rnd((n, L, k + 1, k + 1, N)), rnd((k * N, p.ks_level, n + 1)),
+                                                variant=args.variant, torus_bits=bits)
+    if world > 1:
+        from concrete_amd.distributed import replicate_server_key
+
+        dk = replicate_server_key(ctx, p, dk if rank == 0 else None, torus_bits=bits)
+    lut = np.zeros((k + 1) * N, dtype=dt)
+    lut[k * N:] = rnd(N)
+    dk.upload_lut(lut)
+    device = torch.device("cuda", local_rank)
+    width = (k * N + 1) if order == "ks_pbs" else (n + 1)
+    tdt = torch.int64 if bits == 64 else torch.int32
+    cts = torch.randint(-2 ** 31, 2 ** 31 - 1, (count, width), dtype=torch.int64, device=device)
+    cts = (cts * 4294967297).to(tdt) if bits == 64 else cts.to(tdt)
+    out = torch.empty_like(cts)
+    dk.reserve(count)
+    stream = torch.cuda.current_stream().cuda_stream
+    step = (lambda: dk.ks_pbs_device(cts, None, out, count, stream)) if order == "ks_pbs" else \
+        (lambda: dk.pbs_ks_device(cts, None, out, count, stream))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dk.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tm = dk.timing_read()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        fpp = flop_per_pbs(p)
+        achieved = count * fpp / (tm["pbs_ms"] * 1e-3) / 1e12 if tm["pbs_ms"] > 0 else 0.0
+        print(json.dumps({
+            "metric": f"bootstraps/sec (node), {pname}", "value": count * world * args.steps / elapsed,
+            "unit": "bootstraps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (random key material and ciphertexts)",
+            "config": {"workload": f"{pname} {'keyswitch+PBS' if order == 'ks_pbs' else 'PBS+keyswitch (gate bootstrap)'}, "
+                                   f"batch {count} per GPU, inputs resident in HBM",
+                       "batch_per_gpu": count, "global_batch": count * world,
+                       "pbs_kernel": {1: "generic", 2: "wave", 3: "block"}.get(dk.variant, str(dk.variant))},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flop_per_bootstrap": fpp,
+                         "kernel_ms": tm["pbs_ms"], "keyswitch_kernel_ms": tm["ks_ms"]},
+            "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,7 +204,12 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=1 << 14, help="ciphertexts per GPU")
     ap.add_argument("--variant", type=int, default=CAMD_PBS_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="2_2", choices=sorted(OTHER_WORKLOADS) + ["2_2"],
+                    help="2_2 (default) is the headline configuration; the others time further configurations of the "
+                         "same path with random key material (timing does not depend on the data)")
     args = ap.parse_args()
+    if args.workload != "2_2":
+        return other_workload(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -218,7 +316,7 @@ def main() -> None:
                 "batch_per_gpu": count,
                 "global_batch": count * world,
                 "parallelism": f"batch sharded over {world} GPU(s); server key broadcast once, no per-step collective",
-                "pbs_kernel": {1: "generic", 2: "wave"}.get(dk.variant, str(dk.variant)),
+                "pbs_kernel": {1: "generic", 2: "wave", 3: "block"}.get(dk.variant, str(dk.variant)),
             },
             "roofline": {
                 "bound": "mfma",
