@@ -37,7 +37,12 @@ namespace {
 
 constexpr int WAVES = 4;          // ciphertexts per workgroup
 constexpr int RADIX = 8;          // points per lane (N = 1024)
-constexpr int ROW = 72;           // padded row of the exchange image, in doubles
+constexpr int ROW = 72;           // padded row of the exchange image, in complex values (16 bytes)
+// The exchange image holds interleaved complex values and is accessed 16 bytes per lane: half
+// the LDS instructions of a planar image. The row padding and the XOR swizzle of the second
+// exchange keep every ds_read_b128 lane group (four non-contiguous groups of 16 lanes) and every
+// ds_write_b128 lane group (eight contiguous groups of 8) on distinct 16-byte bank units.
+#define XC(plane) ((double2*)(plane))
 constexpr int PLANE = RADIX * ROW;
 
 // table layout, in double2 entries
@@ -96,8 +101,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
 #if CAMD_ABLATE != 1
 #pragma unroll
   for (int b = 0; b < 8; b++) {
-    sre[b * ROW + lane] = x[b].x;
-    sim[b * ROW + lane] = x[b].y;
+    sre[b * ROW + lane] = x[b].x; sim[b * ROW + lane] = x[b].y;
   }
 #pragma unroll
   for (int q = 0; q < 8; q++) {
@@ -113,8 +117,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
 #pragma unroll
   for (int b = 0; b < 8; b++) {
     const int idx = hi * ROW + b * 8 + (lo ^ b);
-    sre[idx] = x[b].x;
-    sim[idx] = x[b].y;
+    sre[idx] = x[b].x; sim[idx] = x[b].y;
   }
 #pragma unroll
   for (int q = 0; q < 8; q++) {
@@ -134,8 +137,7 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + lo * 8 + (q ^ lo);
-    sre[idx] = x[q].x;
-    sim[idx] = x[q].y;
+    sre[idx] = x[q].x; sim[idx] = x[q].y;
   }
 #pragma unroll
   for (int b = 0; b < 8; b++) {
@@ -150,8 +152,7 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + q * 8 + lo;
-    sre[idx] = x[q].x;
-    sim[idx] = x[q].y;
+    sre[idx] = x[q].x; sim[idx] = x[q].y;
   }
 #pragma unroll
   for (int b = 0; b < 8; b++) x[b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
@@ -479,8 +480,7 @@ __device__ __forceinline__ void fft512_forward_multi(double2 (&x)[S][8], int lan
   for (int s = 0; s < S; s++) {
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-      sre[b * ROW + lane] = x[s][b].x;
-      sim[b * ROW + lane] = x[s][b].y;
+      sre[b * ROW + lane] = x[s][b].x; sim[b * ROW + lane] = x[s][b].y;
     }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -501,8 +501,7 @@ __device__ __forceinline__ void fft512_forward_multi(double2 (&x)[S][8], int lan
 #pragma unroll
     for (int b = 0; b < 8; b++) {
       const int idx = hi * ROW + b * 8 + (lo ^ b);
-      sre[idx] = x[s][b].x;
-      sim[idx] = x[s][b].y;
+      sre[idx] = x[s][b].x; sim[idx] = x[s][b].y;
     }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -535,8 +534,7 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const int idx = hi * ROW + lo * 8 + (q ^ lo);
-      sre[idx] = x[s][q].x;
-      sim[idx] = x[s][q].y;
+      sre[idx] = x[s][q].x; sim[idx] = x[s][q].y;
     }
 #pragma unroll
     for (int b = 0; b < 8; b++) {
@@ -558,8 +556,7 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const int idx = hi * ROW + q * 8 + lo;
-      sre[idx] = x[s][q].x;
-      sim[idx] = x[s][q].y;
+      sre[idx] = x[s][q].x; sim[idx] = x[s][q].y;
     }
 #pragma unroll
     for (int b = 0; b < 8; b++) x[s][b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
@@ -666,21 +663,11 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
     double2 x[R][8];
     v4u bqv[NS - NA > 0 ? NS - NA : 1][8];
     if (work) {
-      // the slabs that do not fit the AGPRs: requested now, needed after the forward transforms
-#pragma unroll
-      for (int sl = NA; sl < NS; sl++) {
-        const char* base = (const char*)(a.fbsk + (size_t)cur * NS * M) + (size_t)sl * (M * sizeof(double2)) + 4096;
-#pragma unroll
-        for (int g = 0; g < 8; g++)
-          asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-                       : "=v"(bqv[sl - NA][g])
-                       : "v"(lane_off), "s"(base), "n"(g * 1024 - 4096)
-                       : "memory");
-      }
       // gather rotated - own, decompose (one level), twist. The LDS reads are issued in units
       // of half a polynomial, one unit ahead of the arithmetic that consumes them, and the
       // order is pinned so that the latency of a unit hides behind the previous unit's work.
       T own0[2][4], own1[2][4], rot0[2][4], rot1[2][4];
+      double2 twg[2][4];  // twist factors travel with the unit: no table read inside the arithmetic
       auto issue = [&](int u) {
         const T* p = ct0 + (u >> 1) * N;
 #pragma unroll
@@ -690,6 +677,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           own1[u & 1][t] = p[j1];
           rot0[u & 1][t] = p[(j0 - a_hat) & (N - 1)];
           rot1[u & 1][t] = p[(j1 - a_hat) & (N - 1)];
+          twg[u & 1][t] = tab[TAB_TWIST + j0];
         }
       };
       auto consume = [&](int u) {
@@ -702,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           uint32_t s0 = digit_state32<T, BL, L>((T)(r0 - own0[u & 1][t]));
           uint32_t s1 = digit_state32<T, BL, L>((T)(r1 - own1[u & 1][t]));
           const int32_t g0 = digit_next32<BL, L>(s0), g1 = digit_next32<BL, L>(s1);
-          x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), tab[TAB_TWIST + j0]);
+          x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), twg[u & 1][t]);
         }
       };
       issue(0);
@@ -715,6 +703,17 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       STAMP(tG)
+      // the slabs that do not fit the AGPRs: requested now, needed after the forward transforms
+#pragma unroll
+      for (int sl = NA; sl < NS; sl++) {
+        const char* base = (const char*)(a.fbsk + (size_t)cur * NS * M) + (size_t)sl * (M * sizeof(double2)) + 4096;
+#pragma unroll
+        for (int g = 0; g < 8; g++)
+          asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                       : "=v"(bqv[sl - NA][g])
+                       : "v"(lane_off), "s"(base), "n"(g * 1024 - 4096)
+                       : "memory");
+      }
       fft512_forward_multi<R>(x, lane, tab, sre, sim);
       STAMP(tF)
       // acc[c] = sum_r GGSW[r][c] * F[r], written over x column by column is not possible
@@ -797,12 +796,14 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
       STAMP(tI)
       // untwist, round, add into the accumulator: old values are read one column ahead
       T old0[2][8], old1[2][8];
+      double2 twr[2][8];
       auto issue_old = [&](int c) {
         const T* pc = ct0 + c * N;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           old0[c & 1][q] = pc[64 * q + lane];
           old1[c & 1][q] = pc[64 * q + lane + M];
+          twr[c & 1][q] = tab[TAB_TWIST + 64 * q + lane];
         }
       };
       issue_old(0);
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const uint32_t j0 = 64 * q + lane;
-          const double2 v = cmul_conj(acc[c][q], tab[TAB_TWIST + j0]);
+          const double2 v = cmul_conj(acc[c][q], twr[c & 1][q]);
           pc[j0] = torus_accumulate(old0[c & 1][q], v.x);
           pc[j0 + M] = torus_accumulate(old1[c & 1][q], v.y);
         }

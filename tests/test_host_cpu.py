@@ -177,3 +177,29 @@ def test_two_process_gloo_plumbing(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("ok") == 2
+
+
+def test_wave_kernel_keeps_parked_key_registers_untouched(tmp_path):
+    """The wave kernel loads next iteration's key rows into accumulation registers with inline
+    assembly, asynchronously: the compiler must never recycle or move those registers (a0..a223)
+    between the load and the multiply-accumulate, or it would copy values that have not landed.
+    It may use the 32 spare ones as spill space. Checked on the generated code."""
+    import re
+    import subprocess
+
+    src = os.path.join(ROOT, "concrete_amd", "csrc", "pbs_wave.hip")
+    out = tmp_path / "pbs_wave.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src,
+                    "-o", str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    start = text.index("wave_pbs_kernel_v2")
+    body = text[text.index(":", start):text.index("s_endpgm", start)]
+    assert "scratch_" not in body and "v_accvgpr_mov_b32" not in body
+    parked = 224
+    writes = [int(m.group(1)) for m in re.finditer(r"v_accvgpr_write_b32 a(\d+),", body)]
+    low = sorted(w for w in writes if w < parked)
+    assert low == list(range(0, parked, 4)), low            # only the zero-initialisation of each register quad
+    for m in re.finditer(r"ds_read\w* a\[(\d+):", body):
+        assert int(m.group(1)) >= parked
+    loads = [int(m.group(1)) for m in re.finditer(r"global_load_dwordx4 a\[(\d+):", body)]
+    assert sorted(loads) == list(range(0, parked, 4))       # one load site per parked quad
