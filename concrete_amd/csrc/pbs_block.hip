@@ -151,6 +151,10 @@ constexpr int group_points(int want, int P) {
   return g;
 }
 
+// accumulator in LDS: the 32-bit torus sets (6-8 KB per ciphertext). Measured both ways: for the
+// 64-bit sets of the same sizes the loss of resident workgroups costs more than the traffic saved.
+constexpr bool block_acc_in_lds(int torus_bytes, int B) { return torus_bytes == 4 && B <= 9; }
+
 constexpr int pass_lo(int B, int PL, int q) { return B - (q + 1) * PL > 0 ? B - (q + 1) * PL : 0; }
 
 // in: x[r] = element r*T + t (natural order). out: x[r] = position (t << PL) | r of the
@@ -260,10 +264,23 @@ void block_pbs_kernel(PbsLaunch<T> a) {
 
   constexpr size_t ST_BYTES = L > 1 ? (size_t)G * sizeof(uint32_t) : 0;
   constexpr size_t SLAB = (size_t)G * sizeof(T) + ST_BYTES + (size_t)(KP1 - CREG) * M * sizeof(double2);
-  char* my = (char*)a.scratch + (size_t)blockIdx.x * SLAB;
-  T* ct0 = (T*)my;                                         // [(k+1)][N]
-  uint32_t* st = (uint32_t*)(my + (size_t)G * sizeof(T));  // [(k+1)][2P][Tn], decomposer states
-  double2* accg = (double2*)(my + (size_t)G * sizeof(T) + ST_BYTES);  // [KP1-CREG][P][Tn]
+  // Boolean sets: the accumulator fits LDS next to the transform image (in the global slab the 16
+  // workgroups of a CU cycle 6 MB per XCD through a 4 MB L2 and the fabric carries 5 TB/s); the
+  // parked decomposer states stay in the slab, LDS for them would cost two resident workgroups.
+  constexpr bool ACC_LDS = block_acc_in_lds((int)sizeof(T), B);
+  T* ct0;        // [(k+1)][N]
+  uint32_t* st;  // [(k+1)][2P][Tn], decomposer states
+  double2* accg = nullptr;  // [KP1-CREG][P][Tn]
+  if constexpr (ACC_LDS) {
+    static_assert(CREG == KP1, "accumulator in LDS is for the boolean sets only");
+    ct0 = (T*)(lds + M + (M >> PL));
+    st = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * SLAB + (size_t)G * sizeof(T));
+  } else {
+    char* my = (char*)a.scratch + (size_t)blockIdx.x * SLAB;
+    ct0 = (T*)my;
+    st = (uint32_t*)(my + (size_t)G * sizeof(T));
+    accg = (double2*)(my + (size_t)G * sizeof(T) + ST_BYTES);
+  }
   const double inv_m = 1.0 / (double)M;
 
   for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
@@ -477,14 +494,17 @@ void block_pbs_kernel(PbsLaunch<T> a) {
 
 int block_pl(uint32_t N) { return N >= 8192 ? 4 : (N >= 1024 ? 3 : (N == 512 ? 2 : 1)); }
 
-size_t block_lds_bytes(uint32_t N) {
+size_t block_lds_bytes(uint32_t N, uint32_t kp1, int torus_bytes, uint32_t level) {
   const uint32_t M = N / 2;
-  return ((size_t)M + (M >> block_pl(N))) * sizeof(double2);
+  size_t bytes = ((size_t)M + (M >> block_pl(N))) * sizeof(double2);
+  if (block_acc_in_lds(torus_bytes, (int)ilog2(M)))
+    bytes += (size_t)kp1 * N * torus_bytes;
+  return bytes;
 }
 
 template <typename T, int B, int PL, int KP1, int LV>
 int block_launch_levels(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream) {
-  const size_t lds = block_lds_bytes(a.N);
+  const size_t lds = block_lds_bytes(a.N, KP1, (int)sizeof(T), LV);
   if (lds > 64 * 1024)
     CAMD_HIP(hipFuncSetAttribute((const void*)block_pbs_kernel<T, B, PL, KP1, LV>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -504,7 +524,7 @@ int block_launch_instance(const PbsLaunch<T>& a, unsigned grid, hipStream_t stre
 
 template <typename T, int B, int PL>
 int block_fourier_instance(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream) {
-  const size_t lds = block_lds_bytes(2u << B);
+  const size_t lds = block_lds_bytes(2u << B, 0, 8, 1);  // the conversion kernel keeps nothing but the image in LDS
   if (lds > 64 * 1024)
     CAMD_HIP(hipFuncSetAttribute((const void*)block_bsk_fourier_kernel<T, B, PL>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -542,7 +562,7 @@ size_t block_scratch_bytes(const camd_params& p, unsigned* grid_out, size_t coun
                       (size_t)(kp1 - creg) * (N / 2) * sizeof(double2);
   const size_t threads = (N / 2) >> block_pl(N);
   size_t per_cu = (size_t)block_waves(block_pl(N), creg) * 256 / threads;  // register budget of the instance
-  const size_t by_lds = (160 * 1024) / block_lds_bytes(N);
+  const size_t by_lds = (160 * 1024) / block_lds_bytes(N, kp1, (int)(p.torus_bits / 8), p.pbs_level);
   if (per_cu > by_lds) per_cu = by_lds;
   if (per_cu < 1) per_cu = 1;
   size_t grid = 256 * per_cu;
