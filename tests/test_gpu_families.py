@@ -184,3 +184,34 @@ def test_device_pointer_entry_points(gpu_ctx):
     assert np.array_equal(dk2.ks_pbs(cts), want)
     dk.close()
     dk2.close()
+
+
+def test_plain_c_caller(gpu_ctx, tmp_path):
+    """The C ABI from a C program (tests/c/abi_driver.c): own process, no Python or torch inside.
+    N = 2048 selects the register-blocked kernel, so the output equals the oracle's bit for bit."""
+    import dataclasses
+    import os
+    import subprocess
+
+    p = P.SHORTINT_BY_NAME["PARAM_MESSAGE_2_CARRY_3"]
+    ks = get_keys(p, 64, n_override=8)
+    o = ks.o
+    lut = o.generate_accumulator(lambda x: (x * 3) % 4)
+    delta = O.shortint_delta(p)
+    cts = np.stack([o.lwe_encrypt(ks.rng, ks.glwe, (m % 32) * delta, ks.lwe_std) for m in range(11)])
+    dp = ks.device_params()
+    header = np.array([dp.lwe_dimension, dp.glwe_dimension, dp.polynomial_size, dp.pbs_base_log, dp.pbs_level,
+                       dp.ks_base_log, dp.ks_level, 64], dtype=np.uint32)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(src, "wb") as f:
+        f.write(header.tobytes())
+        f.write(np.uint64(cts.shape[0]).tobytes())
+        for arr in (ks.bsk, ks.ksk, lut, cts):
+            f.write(np.ascontiguousarray(arr, dtype=np.uint64).tobytes())
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "c", "abi_driver")
+    res = subprocess.run([exe, str(src), str(dst)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "kernel variant 3" in res.stdout
+    got = np.fromfile(dst, dtype=np.uint64).reshape(cts.shape)
+    want = o.ks_pbs_batch(ks.ksk, ks.fbsk, lut, None, cts, threads=4)
+    assert np.array_equal(got, want)

@@ -203,3 +203,16 @@ def test_wave_kernel_keeps_parked_key_registers_untouched(tmp_path):
         assert int(m.group(1)) >= parked
     loads = [int(m.group(1)) for m in re.finditer(r"global_load_dwordx4 a\[(\d+):", body)]
     assert sorted(loads) == list(range(0, parked, 4))       # one load site per parked quad
+
+
+def test_headers_are_plain_c_and_the_c_driver_links():
+    """include/*.h must be consumable by a C99 compiler (they are what a Rust `-sys` crate or a C
+    host binds), and the plain-C driver used by the GPU test must link against the library."""
+    import subprocess
+
+    inc = os.path.join(ROOT, "include")
+    for h in ("concrete_amd.h", "concrete_amd_client.h"):
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                        os.path.join(inc, h)], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "c"), "-s"], check=True, capture_output=True)
+    assert os.path.exists(os.path.join(ROOT, "tests", "c", "abi_driver"))
