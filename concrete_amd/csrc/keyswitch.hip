@@ -12,7 +12,7 @@
 // that bound is reached (for every parameter set of the reference: once, at the end), so the
 // result is bit for bit the integer one. One multiply-add is then one FMA per limb.
 //
-// Tiling: one workgroup owns CT_TILE ciphertexts and 512 output columns; each key word fetched
+// Tiling: one workgroup owns CT_TILE ciphertexts and 256 output columns; each key word fetched
 // (from L2 / Infinity Cache) is used CT_TILE times. Mask elements are decomposed once per chunk
 // into LDS, already converted to f64, and read back as broadcasts.
 #include "kernels.hpp"
@@ -23,7 +23,7 @@ namespace {
 
 constexpr int KS_THREADS = 256;
 constexpr int KS_CT_TILE = 16;    // ciphertexts per workgroup
-constexpr int KS_COLS = 2;        // output columns per thread
+constexpr int KS_COLS = 1;        // output columns per thread
 constexpr int KS_CHUNK = 32;      // mask elements decomposed per LDS refill
 constexpr int KS_MAX_LEVEL = 8;
 
@@ -35,7 +35,7 @@ __device__ __forceinline__ uint64_t exact_to_u64(double v) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(
+__global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void keyswitch_kernel(
     const T* __restrict__ ct_in, size_t in_stride, T* __restrict__ ct_out, size_t out_stride,
     const T* __restrict__ ksk, uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level,
     size_t count, uint32_t flush_chunks) {
@@ -94,7 +94,10 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(
       const uint32_t col = col_base + q * KS_THREADS + tid;
       kv[q] = (col < ncols) ? row0[col] : T(0);
     }
-    for (uint32_t rr = 0; rr < rows; rr++) {
+    // a wave whose columns all lie past the end (the last column block is mostly empty: n+1 is
+    // rarely a multiple of the block) skips the products; it still takes part in the barriers
+    const bool wave_active = col_base + (tid & ~63u) < ncols;
+    for (uint32_t rr = 0; wave_active && rr < rows; rr++) {
       double kf[KS_COLS][LIMBS];
 #pragma unroll
       for (int q = 0; q < KS_COLS; q++) {
