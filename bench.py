@@ -215,7 +215,10 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # CAMD_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL process group, key broadcast,
+    # barriers, max-reduce of the time) with a single rank: a rehearsal on a one-GPU box
+    use_dist = world > 1 or os.environ.get("CAMD_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -238,7 +241,7 @@ def main() -> None:
         ksk = CL.gen_keyswitch_key(cks._rng, p, 64, cks.lwe_secret_key, cks.lwe_secret_key_after_ks)
         dk = DeviceServerKey.from_standard_keys(ctx, p, bsk, ksk, variant=args.variant)
     key_broadcast_ms = None
-    if world > 1:
+    if use_dist:
         from concrete_amd.distributed import replicate_server_key
 
         torch.cuda.synchronize()
