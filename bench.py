@@ -204,6 +204,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=1 << 14, help="ciphertexts per GPU")
     ap.add_argument("--variant", type=int, default=CAMD_PBS_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--luts", type=int, default=1, help="number of distinct look-up tables spread over the batch")
     ap.add_argument("--workload", default="2_2", choices=sorted(OTHER_WORKLOADS) + ["2_2"],
                     help="2_2 (default) is the headline configuration; the others time further configurations of the "
                          "same path with random key material (timing does not depend on the data)")
@@ -254,14 +255,22 @@ def main() -> None:
 
     lut = CL.shortint_accumulator(p, lambda x: x % p.message_modulus)
     dk.upload_lut(lut)
+    # further tables x -> (x + j) % message_modulus, ciphertext i uses table i % luts
+    lut_fns = [(lambda x, j=j: (x + j) % p.message_modulus) for j in range(args.luts)]
+    for f in lut_fns[1:]:
+        dk.upload_lut(CL.shortint_accumulator(p, f))
 
     cts, msgs = make_inputs(cks, count, device, seed=1 + rank)
     out = torch.empty_like(cts)
     dk.reserve(count)
     stream = torch.cuda.current_stream().cuda_stream
 
+    lut_ids = None
+    if args.luts > 1:
+        lut_ids = (torch.arange(count, device=device) % args.luts).to(torch.int32)
+
     def step():
-        dk.ks_pbs_device(cts, None, out, count, stream)
+        dk.ks_pbs_device(cts, lut_ids, out, count, stream)
 
     for _ in range(args.warmup):
         step()
@@ -288,7 +297,10 @@ def main() -> None:
 
     # ---- self-check: every output decrypts to f(m) ----
     got = decode_outputs(cks, out)
-    wrong = int((got != (msgs % p.message_modulus)).sum().item())
+    expect = msgs % p.message_modulus
+    if args.luts > 1:
+        expect = (msgs + torch.arange(count, device=device) % args.luts) % p.message_modulus
+    wrong = int((got != expect).sum().item())
     if dist is not None:
         w = torch.tensor([wrong], dtype=torch.int64, device=device)
         dist.all_reduce(w)
@@ -315,7 +327,8 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": "concrete-shortint PARAM_MESSAGE_2_CARRY_2 keyswitch+PBS, batch 2^14 fresh ciphertexts per GPU, "
-                            "inputs resident in HBM, one shared look-up table (x % 4)",
+                            "inputs resident in HBM, " + ("one shared look-up table (x % 4)" if args.luts == 1 else
+                                                         f"{args.luts} look-up tables interleaved over the batch"),
                 "batch_per_gpu": count,
                 "global_batch": count * world,
                 "parallelism": f"batch sharded over {world} GPU(s); server key broadcast once, no per-step collective",
@@ -344,7 +357,7 @@ def main() -> None:
             "key_setup_s": key_setup_s,
             "key_broadcast_ms": key_broadcast_ms,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.luts == 1:
             cores = min(16, os.cpu_count() or 1)
             sample = cts[: min(count, CPU_SAMPLE)].cpu().numpy().view(np.uint64)
             line["cpu_baseline"], cpu_out = cpu_baseline(p, bsk, ksk, lut, sample, cores)
