@@ -213,7 +213,27 @@ class ServerKey:
         return Ciphertext(lwe=self.bootstrapper.keyswitch(summed)[0])
 
     # ---- batched gates: arrays [count][n+1] of encrypted inputs ----
-    def gate_batch(self, gate: str, a: np.ndarray, b: np.ndarray) -> np.ndarray:
-        a = np.ascontiguousarray(a, dtype=np.uint32)
-        b = np.ascontiguousarray(b, dtype=np.uint32)
-        return self.bootstrapper.bootstrap_keyswitch(self._combine(gate, a, b))
+    # linear part of each gate as (alpha, beta, plaintext) of alpha*a + beta*b + plaintext, then an
+    # optional doubling: engine/mod.rs:347-353, :388-397, :431-440, :472-478, :515-525, :558-572
+    _LINEAR = {"and": (1, 1, int(PLAINTEXT_FALSE)), "nand": (-1, -1, int(PLAINTEXT_TRUE)),
+               "nor": (-1, -1, int(PLAINTEXT_FALSE)), "or": (1, 1, int(PLAINTEXT_TRUE)),
+               "xor": (2, 2, 2 * int(PLAINTEXT_TRUE)), "xnor": (-2, -2, -2 * int(PLAINTEXT_TRUE))}
+
+    def gate_batch(self, gate: str, a, b):
+        """One gate on many ciphertext pairs. Host arrays ([count][n+1] uint32) go through the host
+        entry point; torch CUDA int32 tensors stay on the GPU: the gate's linear combination is one
+        ``camd_lwe_axpby_device`` pass and the bootstrap + keyswitch reads its output in place."""
+        if isinstance(a, np.ndarray):
+            a = np.ascontiguousarray(a, dtype=np.uint32)
+            b = np.ascontiguousarray(b, dtype=np.uint32)
+            return self.bootstrapper.bootstrap_keyswitch(self._combine(gate, a, b))
+        import torch
+
+        alpha, beta, plain = self._LINEAR[gate]
+        key = self.bootstrapper.key
+        stream = torch.cuda.current_stream().cuda_stream
+        mixed = torch.empty_like(a)
+        key.ctx.lwe_axpby_device(mixed, a, alpha, b, beta, plain, 32, stream)
+        out = torch.empty_like(a)
+        key.pbs_ks_device(mixed, None, out, a.shape[0], stream)
+        return out

@@ -105,3 +105,27 @@ def test_boolean_gates_and_mux(gpu_ctx):
         cts[i] = getattr(sks, g)(cts[i], cts[j])
         vals[i] = clear[g](vals[i], vals[j])
     assert [cks.decrypt(c) for c in cts] == vals
+
+
+def test_boolean_gate_batches_on_device(gpu_ctx):
+    """Every gate on a device-resident batch (linear part by camd_lwe_axpby_device, 32-bit torus)
+    equals the host path ciphertext for ciphertext, and decrypts to the truth table."""
+    import torch
+
+    import concrete_amd.parameters as P
+    from concrete_amd import boolean as B
+
+    cks = B.ClientKey(P.DEFAULT_PARAMETERS, seed=5)
+    sks = B.ServerKey.new(cks, ctx=gpu_ctx)
+    bits_a = np.array([0, 0, 1, 1] * 8, dtype=bool)
+    bits_b = np.array([0, 1, 0, 1] * 8, dtype=bool)
+    ca, cb = cks.encrypt_batch(bits_a), cks.encrypt_batch(bits_b)
+    da = torch.from_numpy(ca.view(np.int32)).cuda()
+    db = torch.from_numpy(cb.view(np.int32)).cuda()
+    clear = {"and": bits_a & bits_b, "nand": ~(bits_a & bits_b), "or": bits_a | bits_b, "nor": ~(bits_a | bits_b),
+             "xor": bits_a ^ bits_b, "xnor": ~(bits_a ^ bits_b)}
+    for gate, want in clear.items():
+        host = sks.gate_batch(gate, ca, cb)
+        dev = sks.gate_batch(gate, da, db).cpu().numpy().view(np.uint32)
+        assert np.array_equal(host, dev), gate
+        assert np.array_equal(cks.decrypt_batch(dev), want), gate
