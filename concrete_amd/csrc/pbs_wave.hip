@@ -861,6 +861,202 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   }
 }
 
+// ---- the bootstrap, third schedule: two waves per SIMD ----
+// The second schedule is held at one wave per SIMD by LDS (24 KB of accumulator per ciphertext)
+// and by the 288 registers of parked key rows. Here the accumulator lives in registers
+// ((k+1) x 16 torus words per lane), the rotation goes through an 8 KB per-wave staging row, and
+// key rows are ordinary loads consumed where they land: a wave needs 17.4 KB of LDS and at most
+// 256 registers, so eight waves (512 threads) share a CU and each SIMD always has a second wave
+// to issue from while the first waits on LDS, memory or a dependent result. No inline-assembly
+// loads: every wait is placed by the compiler. The multiply-accumulate works in place, one
+// frequency register at a time (its k+1 inputs are consumed to produce its k+1 outputs).
+//
+// Measured: 128 ms per 2^14 bootstraps against 119 ms for the second schedule, so this one is not
+// the default (CAMD_WAVE_SCHEDULE=3 selects it). With 256 registers per wave there is room for
+// only one step of key prefetch (12 products) against an L2 latency of several hundred cycles:
+// the multiply-accumulate becomes latency-bound and both waves of a SIMD sit in it together.
+// Parking a whole iteration of key rows, as the second schedule does, needs the 288 registers
+// that only a lone wave has.
+constexpr int WAVES3 = 8;
+
+template <typename T, int K>
+constexpr size_t wave3_slab_bytes() {
+  return 2 * PLANE * sizeof(double) + 1024 * sizeof(T);
+}
+template <typename T, int K>
+constexpr size_t wave3_lds_bytes() {
+  return TAB_COUNT * sizeof(double2) + WAVES3 * wave3_slab_bytes<T, K>();
+}
+
+template <typename T, int K, int BL>
+__global__ __launch_bounds__(64 * WAVES3) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void wave_pbs_kernel_v3(PbsLaunch<T> a) {
+  constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1, NS = R * R;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * WAVES3) tab[t] = a.tables[t];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * wave3_slab_bytes<T, K>();
+  double* sre = (double*)slab;
+  double* sim = sre + PLANE;
+  T* stage = (T*)(slab + 2 * PLANE * sizeof(double));
+  const uint32_t n = a.n;
+
+  // persistent waves with a per-XCD quorum rendezvous between ciphertexts (see the second schedule)
+  const uint32_t group = blockIdx.x % SYNC_GROUPS;
+  const uint32_t group_waves = ((gridDim.x - group + SYNC_GROUPS - 1) / SYNC_GROUPS) * WAVES3;
+  uint32_t* arrivals = (uint32_t*)a.scratch + group * SYNC_STRIDE;
+  const size_t per_round = (size_t)gridDim.x * WAVES3;
+  uint32_t round = 0;
+  for (size_t ct = (size_t)blockIdx.x * WAVES3 + wave; ct < a.count; ct += per_round, round++) {
+    const T* in = a.ct_in + ct * a.in_stride;
+    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
+    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N);
+
+    // accumulator: acc[c][2q] = coefficient 64q + lane, acc[c][2q+1] = coefficient 64q + lane + N/2
+    T acc[R][16];
+    {
+      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+#pragma unroll
+      for (int c = 0; c < R; c++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          acc[c][2 * q] = rotated_coeff<T>(lut + (size_t)c * N, 64 * q + lane, d0, N);
+          acc[c][2 * q + 1] = rotated_coeff<T>(lut + (size_t)c * N, 64 * q + lane + M, d0, N);
+        }
+    }
+
+    T a_next = wave_uniform(in[0]);
+    for (uint32_t i = 0; i < n; i++) {
+      const T a_cur = a_next;
+      a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
+      if (a_cur == 0) continue;           // the reference skips these too
+      const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
+      // opaque copy of the lane index: LDS and table addresses are recomputed per iteration (one
+      // add each) instead of being hoisted out of the loop, where they would crowd out the
+      // accumulator and be spilled
+      int lane_i = lane;
+      asm volatile("" : "+v"(lane_i));
+#define lane lane_i
+
+      double2 x[R][8];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        // rotation by X^a_hat: the polynomial is laid out once in the staging row and read back
+        // at the rotated index (the wave's LDS operations complete in order)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          stage[64 * q + lane] = acc[r][2 * q];
+          stage[64 * q + lane + M] = acc[r][2 * q + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+          const T v0 = stage[(j0 - a_hat) & (N - 1)], v1 = stage[(j1 - a_hat) & (N - 1)];
+          const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - v0) : v0;
+          const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - v1) : v1;
+          uint32_t s0 = digit_state32<T, BL, L>((T)(r0 - acc[r][2 * q]));
+          uint32_t s1 = digit_state32<T, BL, L>((T)(r1 - acc[r][2 * q + 1]));
+          const int32_t g0 = digit_next32<BL, L>(s0), g1 = digit_next32<BL, L>(s1);
+          x[r][q] = cmul(make_double2((double)g0, (double)g1), tab[TAB_TWIST + j0]);
+          if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // at most two points' reads in flight
+        }
+      }
+      // one transform after the other: with a second wave on the SIMD, interleaving the streams
+      // buys nothing and costs the registers the accumulator needs
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        __builtin_amdgcn_sched_barrier(0);
+        fft512_forward(x[r], lane, tab, sre, sim);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // x[c][g] <- sum_r key[r][c][g] * x[r][g], one frequency register at a time
+      const double2* key = a.fbsk + (size_t)i * NS * M + lane;
+      // flattened over (register g, output column c): the k+1 key values of step t+1 are
+      // requested before the products of step t, so 2(k+1) complex values are in flight instead
+      // of whole rows; the fences keep the compiler from hoisting all 72 loads and spilling the
+      // accumulator to make room
+      double2 kk[2][R];
+      auto issue_keys = [&](int t) {
+        const int g = t / R, c = t % R;
+#pragma unroll
+        for (int r = 0; r < R; r++) kk[t & 1][r] = key[(size_t)(r * R + c) * M + g * 64];
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      issue_keys(0);
+      double2 in_g[R];
+#pragma unroll
+      for (int t = 0; t < 8 * R; t++) {
+        const int g = t / R, c = t % R;
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < 8 * R) issue_keys(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 0) {
+#pragma unroll
+          for (int r = 0; r < R; r++) in_g[r] = x[r][g];
+        }
+        double2 v = cmul(kk[t & 1][0], in_g[0]);
+#pragma unroll
+        for (int r = 1; r < R; r++) v = cfma(kk[t & 1][r], in_g[r], v);
+        x[c][g] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < R; c++) {
+        __builtin_amdgcn_sched_barrier(0);
+        fft512_inverse(x[c], lane, tab, sre, sim);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // The staging row still holds the last polynomial exactly as the gather laid it out: its
+      // registers are free during the transforms and the multiply-accumulate, and it is read
+      // back here (32 fewer live registers where the pressure peaks).
+#pragma unroll
+      for (int c = 0; c < R; c++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          if (c == R - 1) {
+            acc[c][2 * q] = stage[64 * q + lane];
+            acc[c][2 * q + 1] = stage[64 * q + lane + M];
+          }
+          const double2 v = cmul_conj(x[c][q], tab[TAB_TWIST + 64 * q + lane]);
+          acc[c][2 * q] = torus_accumulate(acc[c][2 * q], v.x);
+          acc[c][2 * q + 1] = torus_accumulate(acc[c][2 * q + 1], v.y);
+          if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+#undef lane
+    }
+
+    // sample extraction of coefficient 0: out[c N + (N - j) mod N] = (j == 0) ? p[j] : -p[j]
+    T* out = a.ct_out + ct * a.out_stride;
+#pragma unroll
+    for (int c = 0; c < K; c++)
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+        out[(size_t)c * N + ((N - j0) & (N - 1))] = (j0 == 0) ? acc[c][2 * q] : (T)(T(0) - acc[c][2 * q]);
+        out[(size_t)c * N + (N - j1)] = (T)(T(0) - acc[c][2 * q + 1]);
+      }
+    if (lane == 0) out[K * N] = acc[K][0];
+
+    if ((size_t)(round + 1) * per_round < a.count) {
+      if (lane == 0) {
+        __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t target = (round + 1) * group_waves - group_waves / WAVE_QUORUM_SLACK;
+        for (uint32_t spin = 0; spin < (1u << 16); spin++) {
+          if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+          __builtin_amdgcn_s_sleep(16);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 template <typename T, int K, int L, int BL>
 int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
   constexpr size_t lds = wave_lds_bytes<T, K>();
@@ -871,6 +1067,24 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     return e ? atoi(e) : 2;
   }();
   if constexpr (L == 1) {
+    if (schedule == 3) {
+      constexpr size_t lds3 = wave3_lds_bytes<T, K>();
+      static_assert(lds3 <= 160 * 1024, "LDS budget exceeded");
+      auto kern3 = wave_pbs_kernel_v3<T, K, BL>;
+      CAMD_HIP(hipFuncSetAttribute((const void*)kern3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      int dev = 0, cus = 0;
+      CAMD_HIP(hipGetDevice(&dev));
+      CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      const unsigned grid3 = (unsigned)((a.count + WAVES3 - 1) / WAVES3);
+      const unsigned persistent = cus > 0 && grid3 > (unsigned)cus ? (unsigned)cus : grid3;
+      if (persistent < grid3) {
+        if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
+        CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
+      }
+      hipLaunchKernelGGL(kern3, dim3(persistent), dim3(64 * WAVES3), lds3, stream, a);
+      CAMD_HIP(hipGetLastError());
+      return CAMD_OK;
+    }
     if (schedule == 2) {
       auto kern2 = wave_pbs_kernel_v2<T, K, BL>;
       CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
