@@ -426,6 +426,43 @@ class ServerKey:
 
     smart_scalar_mul_parallelized = smart_scalar_mul
 
+    # ----------------------------------------------------------------- shift.rs --
+    def unchecked_scalar_left_shift(self, ct: RadixCiphertext, shift: int) -> RadixCiphertext:
+        res = ct.clone()
+        self.unchecked_scalar_left_shift_assign(res, shift)
+        return res
+
+    def unchecked_scalar_left_shift_assign(self, ct: RadixCiphertext, shift: int) -> None:
+        """radix/shift.rs:196-199: multiplication by 2^shift."""
+        self.smart_scalar_mul_assign(ct, 1 << shift)
+
+    def _partial_propagate(self, ctxt: RadixCiphertext) -> None:
+        for i in range(len(ctxt.blocks) - 1):
+            self.propagate(ctxt, i)
+
+    def unchecked_scalar_right_shift(self, ct: RadixCiphertext, shift: int) -> RadixCiphertext:
+        res = ct.clone()
+        self.unchecked_scalar_right_shift_assign(res, shift)
+        return res
+
+    def unchecked_scalar_right_shift_assign(self, ct: RadixCiphertext, shift: int) -> None:
+        """radix/shift.rs:106-136: a right shift by u = p*q + r bits (p bits per block) is a left
+        shift by p - r bits followed by a shift of q + 1 whole blocks."""
+        nb_bits = self.key.message_modulus.bit_length() - 1
+        quotient, remainder = divmod(int(shift), nb_bits)
+        if remainder == 0:
+            self.full_propagate(ct)
+            ct.blocks = self.blockshift_right(ct, quotient).blocks
+        else:
+            self.unchecked_scalar_left_shift_assign(ct, nb_bits - remainder)
+            self._partial_propagate(ct)
+            ct.blocks = self.blockshift_right(ct, 1).blocks
+            self.propagate(ct, len(ct.blocks) - 2)
+            ct.blocks = self.blockshift_right(ct, quotient).blocks
+
+    unchecked_scalar_left_shift_parallelized = unchecked_scalar_left_shift
+    unchecked_scalar_right_shift_parallelized = unchecked_scalar_right_shift
+
     # ------------------------------------------------------------------- mul.rs --
     def _block_mul_parts(self, ct1: RadixCiphertext, ct2_block: _si.Ciphertext, index: int):
         """radix/mul.rs:54-76: low and high halves of ct1 * (one block of ct2), the bootstraps

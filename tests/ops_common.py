@@ -237,6 +237,10 @@ def check_radix_ops(cks, sks, count=6, device=False, seed=3, num_blocks=4, tally
     t.eq(dec(isks.smart_bitand(cx.clone(), cy.clone())), x & y)
     t.eq(dec(isks.smart_bitor(cx.clone(), cy.clone())), x | y)
     t.eq(dec(isks.smart_bitxor(acc, cy.clone())), clear ^ y)
+    # shifts (radix/tests.rs: the value is shifted inside the modulus)
+    for sh in (1, 2, 3, 5):
+        t.eq(dec(isks.unchecked_scalar_left_shift(cx.clone(), sh)), (x << np.uint64(sh)) % mod)
+        t.eq(dec(isks.unchecked_scalar_right_shift(cx.clone(), sh)), x >> np.uint64(sh))
     # single integers go through the same code (reference signatures)
     one = icks.encrypt(201)
     two = icks.encrypt(77)

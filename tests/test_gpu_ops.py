@@ -23,7 +23,7 @@ def test_shortint_operation_layer(gpu_keys, device):
 @pytest.mark.parametrize("device", [False, True])
 def test_radix_fheuint8(gpu_keys, device):
     cks, sks = gpu_keys
-    OC.check_radix_ops(cks, sks, count=48, device=device, tally=OC.Tally(per_check=2, total=6))
+    OC.check_radix_ops(cks, sks, count=48, device=device, tally=OC.Tally(per_check=2, total=8))
 
 
 def test_lwe_axpby_strided_views(gpu_ctx):
