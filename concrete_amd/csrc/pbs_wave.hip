@@ -871,13 +871,16 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
 // loads: every wait is placed by the compiler. The multiply-accumulate works in place, one
 // frequency register at a time (its k+1 inputs are consumed to produce its k+1 outputs).
 //
-// Measured: 128 ms per 2^14 bootstraps against 119 ms for the second schedule, so this one is not
-// the default (CAMD_WAVE_SCHEDULE=3 selects it). With 256 registers per wave there is room for
-// only one step of key prefetch (12 products) against an L2 latency of several hundred cycles:
-// the multiply-accumulate becomes latency-bound and both waves of a SIMD sit in it together.
-// Parking a whole iteration of key rows, as the second schedule does, needs the 288 registers
-// that only a lone wave has.
+// Measured: 121-124 ms per 2^14 bootstraps against 119 ms for the second schedule, so this one is
+// not the default (CAMD_WAVE_SCHEDULE=3 selects it). With 256 registers per wave there is room
+// for three steps of key prefetch (36 products) against an L2 latency of several hundred cycles,
+// and the compiler still spills some forty registers whose reloads wait behind the key loads;
+// the vector ALU of a SIMD is busy 60 % of the time with its two waves. Parking a whole
+// iteration of key rows, as the second schedule does, needs the 288 registers only a lone wave has.
 constexpr int WAVES3 = 8;
+#ifndef WAVE3_KEY_AHEAD
+#define WAVE3_KEY_AHEAD 3
+#endif
 
 template <typename T, int K>
 constexpr size_t wave3_slab_bytes() {
@@ -944,6 +947,7 @@ void wave_pbs_kernel_v3(PbsLaunch<T> a) {
 #define lane lane_i
 
       double2 x[R][8];
+      int32_t dg[R][16];  // digits wait as integers (half the registers) until their transform starts
 #pragma unroll
       for (int r = 0; r < R; r++) {
         // rotation by X^a_hat: the polynomial is laid out once in the staging row and read back
@@ -961,8 +965,8 @@ void wave_pbs_kernel_v3(PbsLaunch<T> a) {
           const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - v1) : v1;
           uint32_t s0 = digit_state32<T, BL, L>((T)(r0 - acc[r][2 * q]));
           uint32_t s1 = digit_state32<T, BL, L>((T)(r1 - acc[r][2 * q + 1]));
-          const int32_t g0 = digit_next32<BL, L>(s0), g1 = digit_next32<BL, L>(s1);
-          x[r][q] = cmul(make_double2((double)g0, (double)g1), tab[TAB_TWIST + j0]);
+          dg[r][2 * q] = digit_next32<BL, L>(s0);
+          dg[r][2 * q + 1] = digit_next32<BL, L>(s1);
           if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // at most two points' reads in flight
         }
       }
@@ -971,6 +975,9 @@ void wave_pbs_kernel_v3(PbsLaunch<T> a) {
 #pragma unroll
       for (int r = 0; r < R; r++) {
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          x[r][q] = cmul(make_double2((double)dg[r][2 * q], (double)dg[r][2 * q + 1]), tab[TAB_TWIST + 64 * q + lane]);
         fft512_forward(x[r], lane, tab, sre, sim);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -981,28 +988,30 @@ void wave_pbs_kernel_v3(PbsLaunch<T> a) {
       // requested before the products of step t, so 2(k+1) complex values are in flight instead
       // of whole rows; the fences keep the compiler from hoisting all 72 loads and spilling the
       // accumulator to make room
-      double2 kk[2][R];
+      constexpr int AHEAD = WAVE3_KEY_AHEAD;  // steps of key values in flight ahead of the products
+      double2 kk[AHEAD + 1][R];
       auto issue_keys = [&](int t) {
         const int g = t / R, c = t % R;
 #pragma unroll
-        for (int r = 0; r < R; r++) kk[t & 1][r] = key[(size_t)(r * R + c) * M + g * 64];
+        for (int r = 0; r < R; r++) kk[t % (AHEAD + 1)][r] = key[(size_t)(r * R + c) * M + g * 64];
       };
       __builtin_amdgcn_sched_barrier(0);
-      issue_keys(0);
+#pragma unroll
+      for (int t = 0; t < AHEAD; t++) issue_keys(t);
       double2 in_g[R];
 #pragma unroll
       for (int t = 0; t < 8 * R; t++) {
         const int g = t / R, c = t % R;
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < 8 * R) issue_keys(t + 1);
+        if (t + AHEAD < 8 * R) issue_keys(t + AHEAD);
         __builtin_amdgcn_sched_barrier(0);
         if (c == 0) {
 #pragma unroll
           for (int r = 0; r < R; r++) in_g[r] = x[r][g];
         }
-        double2 v = cmul(kk[t & 1][0], in_g[0]);
+        double2 v = cmul(kk[t % (AHEAD + 1)][0], in_g[0]);
 #pragma unroll
-        for (int r = 1; r < R; r++) v = cfma(kk[t & 1][r], in_g[r], v);
+        for (int r = 1; r < R; r++) v = cfma(kk[t % (AHEAD + 1)][r], in_g[r], v);
         x[c][g] = v;
       }
       __builtin_amdgcn_sched_barrier(0);
