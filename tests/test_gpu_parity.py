@@ -205,3 +205,22 @@ def test_wave_persistent_rounds_and_tail(gpu_ctx, keys_2_2):
     dec = lambda out: np.array([O.shortint_decode(p, int(ph)) for ph in CL.lwe_phase(64, ks.glwe, out)])
     assert np.array_equal(dec(got), dec(want))
     assert np.count_nonzero(dec(got) != (3 * msgs) % 4) <= 3   # the parameter set's own failure rate
+
+
+def test_other_wave_schedules_in_their_own_process():
+    """The schedule of the wave family is chosen once per process (CAMD_WAVE_SCHEDULE); the first
+    (one row at a time) and third (two waves per SIMD) schedules are kept as selectable variants and
+    must meet the same parity bar as the default."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("CAMD_WAVE_SCHEDULE"):
+        pytest.skip("already running under a non-default schedule")
+    here = os.path.abspath(__file__)
+    for schedule in ("1", "3"):
+        env = dict(os.environ, CAMD_WAVE_SCHEDULE=schedule)
+        res = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
+                              "ks_pbs_parity_2_2 or trivial_bootstrap or persistent_rounds", "-p", "no:cacheprovider"],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, f"schedule {schedule}:\n" + res.stdout[-3000:] + res.stderr[-2000:]
