@@ -115,6 +115,25 @@ class DeviceServerKey:
             raise ValueError("destination tensor is smaller than the key blob")
         check(_ffi.lib().camd_server_key_export_blob(self._h, C.c_void_p(dst.data_ptr()), C.c_void_p(stream)))
 
+    def export_blob_host(self) -> np.ndarray:
+        """The key material as host bytes (uint8 array): what a key file stores."""
+        out = np.empty(self.blob_size(), dtype=np.uint8)
+        check(_ffi.lib().camd_server_key_export_blob(self._h, _np_ptr(out), C.c_void_p(0)))
+        self.ctx.synchronize()
+        return out
+
+    @classmethod
+    def from_host_blob(cls, ctx: Context, params, blob: np.ndarray, variant: int,
+                       torus_bits: int | None = None) -> "DeviceServerKey":
+        """Rebuild a key from ``export_blob_host`` bytes; ``variant`` must be the exporting key's."""
+        bits = torus_bits if torus_bits is not None else int(getattr(params, "torus_bits", 64))
+        data = np.ascontiguousarray(blob, dtype=np.uint8)
+        cp = _ffi.make_params(params, bits)
+        h = C.c_void_p()
+        check(_ffi.lib().camd_server_key_import_blob(ctx._h, C.byref(cp), int(variant), _np_ptr(data), data.size,
+                                                     C.c_void_p(0), C.byref(h)))
+        return cls(ctx, h, params, bits)
+
     def close(self) -> None:
         if self._h:
             _ffi.lib().camd_server_key_destroy(self._h)

@@ -105,7 +105,11 @@ class ServerKey:
         ksk = _client.gen_keyswitch_key(cks._rng, p, 32, cks.glwe_secret_key, cks.lwe_secret_key)
         ctx = ctx or Context(0)
         dk = DeviceServerKey.from_standard_keys(ctx, p, bsk, ksk, variant=variant, torus_bits=32)
-        return cls(GpuBootstrapper(dk, p))
+        sks = cls(GpuBootstrapper(dk, p))
+        # kept on the host like the reference's CpuBootstrapKey (cpu.rs:78-82): the serialized
+        # form of a boolean server key is the standard-domain key (cpu.rs:262-290)
+        sks.standard_bootstrap_key, sks.key_switching_key = bsk, ksk
+        return sks
 
     # ---- helpers ----
     def _lwe_of(self, ct: Ciphertext) -> np.ndarray:

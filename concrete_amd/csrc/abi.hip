@@ -453,7 +453,7 @@ int camd_server_key_blob_size(const camd_server_key* key, size_t* bytes) {
 int camd_server_key_export_blob(const camd_server_key* key, void* device_dst, void* stream) {
   if (!key || !device_dst) return fail(CAMD_EINVAL, "null argument");
   DeviceGuard g(key->ctx->device);
-  CAMD_HIP(hipMemcpyAsync(device_dst, key->blob, key->fbsk_bytes + key->ksk_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  CAMD_HIP(hipMemcpyAsync(device_dst, key->blob, key->fbsk_bytes + key->ksk_bytes, hipMemcpyDefault, (hipStream_t)stream));
   return CAMD_OK;
 }
 
@@ -472,7 +472,7 @@ int camd_server_key_import_blob(camd_context* ctx, const camd_params* params, in
   camd_server_key* key = nullptr;
   rc = key_alloc(ctx, *params, variant, &key);
   if (rc != CAMD_OK) return rc;
-  hipError_t e = hipMemcpyAsync(key->blob, device_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  hipError_t e = hipMemcpyAsync(key->blob, device_src, bytes, hipMemcpyDefault, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   if (e != hipSuccess) {
     key_free(key);

@@ -55,6 +55,13 @@ class ClientKey:
     def new(cls, parameters, seed: int = 0) -> "ClientKey":
         return cls(parameters, seed)
 
+    @classmethod
+    def from_shortint(cls, key: _si.ClientKey) -> "ClientKey":
+        """client_key/mod.rs:31-35 (``From<ShortintClientKey>``)."""
+        self = cls.__new__(cls)
+        self.key = key
+        return self
+
     def parameters(self):
         return self.key.parameters
 

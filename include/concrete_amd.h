@@ -84,8 +84,12 @@ int camd_server_key_variant(const camd_server_key* key, int* variant);
 
 /* Device-resident key material as one blob (Fourier bootstrap key, keyswitch key), so that a
  * key built on one GPU can be replicated to others with one broadcast and no second FFT.
- * export copies the blob into `device_dst` (device pointer, >= blob size) on `stream`;
- * import builds a key around a copy of `device_src`. The variant and params must match. */
+ * export copies the blob into `device_dst` (>= blob size) on `stream`; import builds a key around
+ * a copy of `device_src`. Both pointers may also be host memory (the copy direction is taken
+ * from the pointer), which is how a key is written to and read back from a file: synchronise
+ * `stream` before reading an exported host buffer. The layout of the Fourier part depends on
+ * the kernel family, so the variant and params given to import must be those of the exporting
+ * key (camd_server_key_variant, camd_server_key_params). */
 int camd_server_key_blob_size(const camd_server_key* key, size_t* bytes);
 int camd_server_key_export_blob(const camd_server_key* key, void* device_dst, void* stream);
 int camd_server_key_import_blob(camd_context* ctx, const camd_params* params, int pbs_variant,
