@@ -135,6 +135,55 @@ class ClientKey:
     def decrypt(self, ct: Ciphertext) -> int:
         return self.decrypt_message_and_carry(ct) % ct.message_modulus
 
+    # ---- encodings without the padding bit, and the native CRT encoding ----
+    def _phases(self, ct: Ciphertext) -> np.ndarray:
+        data = ct.ct if isinstance(ct.ct, np.ndarray) else ct.ct.cpu().numpy().view(np.uint64)
+        return _client.lwe_phase(64, self.lwe_secret_key, np.ascontiguousarray(data))
+
+    @staticmethod
+    def _shape(ct: Ciphertext, values: list):
+        return values[0] if ct.ct.ndim == 1 else np.array(values, dtype=np.int64)
+
+    def encrypt_without_padding(self, message: int) -> Ciphertext:
+        """engine/client_side.rs:146-175: the scaling is doubled, the message is not reduced."""
+        p = self.parameters
+        pt = (int(message) * self._delta * 2) & 0xFFFFFFFFFFFFFFFF
+        ct = _client.lwe_encrypt(self._rng, 64, self.lwe_secret_key, [pt], p.lwe_modular_std_dev)[0]
+        return Ciphertext(ct, p.message_modulus - 1, p.message_modulus, p.carry_modulus)
+
+    def decrypt_message_and_carry_without_padding(self, ct: Ciphertext):
+        """engine/client_side.rs:177-203."""
+        delta = self._delta * 2
+        out = []
+        for ph in self._phases(ct):
+            rounding = (int(ph) & (delta >> 1)) << 1
+            out.append(((int(ph) + rounding) & 0xFFFFFFFFFFFFFFFF) // delta)
+        return self._shape(ct, out)
+
+    def decrypt_without_padding(self, ct: Ciphertext):
+        """engine/client_side.rs:205-212."""
+        return self.decrypt_message_and_carry_without_padding(ct) % ct.message_modulus
+
+    def encrypt_native_crt(self, message: int, message_modulus: int) -> Ciphertext:
+        """engine/client_side.rs:214-241: the whole torus is split into ``message_modulus`` parts
+        (128-bit intermediate, floor division), carry modulus 1."""
+        p = self.parameters
+        message_modulus = int(message_modulus) & 0xFF
+        m = int(message) % message_modulus
+        pt = ((m << 64) // message_modulus) & 0xFFFFFFFFFFFFFFFF
+        ct = _client.lwe_encrypt(self._rng, 64, self.lwe_secret_key, [pt], p.lwe_modular_std_dev)[0]
+        return Ciphertext(ct, message_modulus - 1, message_modulus, 1)
+
+    def decrypt_message_native_crt(self, ct: Ciphertext, message_modulus: int):
+        """engine/client_side.rs:243-262 (u128 arithmetic: the product cannot wrap)."""
+        basis = int(message_modulus) & 0xFF
+        out = []
+        for ph in self._phases(ct):
+            result = int(ph) * basis
+            result = (result + ((result & (1 << 63)) << 1)) >> 64
+            out.append((result & 0xFFFFFFFFFFFFFFFF) % basis)
+        return self._shape(ct, out)
+
     def decrypt_message_and_carry_batch(self, cts: np.ndarray) -> np.ndarray:
         phases = _client.lwe_phase(64, self.lwe_secret_key, cts)
         return np.array([self.decode(int(ph)) for ph in phases], dtype=np.int64)
@@ -168,6 +217,14 @@ class ServerKey(ShortintOps):
         bsk = _client.gen_bootstrap_key(cks._rng, p, 64, cks.lwe_secret_key_after_ks, cks.glwe_secret_key, threads=threads)
         ksk = _client.gen_keyswitch_key(cks._rng, p, 64, cks.lwe_secret_key, cks.lwe_secret_key_after_ks)
         return cls.from_standard_keys(p, bsk, ksk, ctx=ctx, variant=variant)
+
+    @classmethod
+    def new_with_max_degree(cls, cks: ClientKey, max_degree: int, ctx: Context | None = None,
+                            variant: int = CAMD_PBS_AUTO) -> "ServerKey":
+        """server_key/mod.rs:86-90 -> engine/server_side/mod.rs:31-72."""
+        sks = cls.new(cks, ctx=ctx, variant=variant)
+        sks.max_degree = int(max_degree)
+        return sks
 
     @classmethod
     def from_standard_keys(cls, parameters, bsk_standard: np.ndarray, ksk: np.ndarray, ctx: Context | None = None,
@@ -283,6 +340,17 @@ class ServerKey(ShortintOps):
             ct = torch.zeros((like.ct.shape[0], words), dtype=torch.int64, device=like.ct.device)
             ct[:, -1] = modular_value * delta
         return Ciphertext(ct, modular_value, self.message_modulus, self.carry_modulus)
+
+    def create_trivial_assign(self, ct: Ciphertext, value: int) -> None:
+        """engine/server_side/mod.rs:284-310. As in the reference, the new ciphertext is sized with
+        the bootstrap key's INPUT dimension (n+1 words; ``create_trivial`` uses the output
+        dimension, :257-261) and the moduli of ``ct`` are left as they are."""
+        modular_value = (int(value) & 0xFF) % self.message_modulus
+        delta = (1 << 63) // (self.message_modulus * self.carry_modulus)
+        words = np.zeros(self.parameters.lwe_dimension + 1, dtype=np.uint64)
+        words[-1] = np.uint64(modular_value * delta)
+        ct.ct = words
+        ct.degree = modular_value
 
     # ---- batched forms ----
     def keyswitch_programmable_bootstrap_batch(self, cts: np.ndarray, accs: Sequence[LookupTable] | LookupTable) -> np.ndarray:

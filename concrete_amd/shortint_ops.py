@@ -287,6 +287,14 @@ class ShortintOps:
         ct.ct = self._lin(ct.ct, 1, body_add=scalar * delta)
         ct.degree += scalar
 
+    def unchecked_scalar_add_assign_crt(self, ct, scalar: int) -> None:
+        """engine/server_side/scalar_add.rs:32-47: the scaling comes from the server key's moduli,
+        not the ciphertext's (ciphertexts of the CRT representation carry their own modulus)."""
+        scalar = int(scalar) & 0xFF
+        delta = (1 << 63) // (self.message_modulus * self.carry_modulus)
+        ct.ct = self._lin(ct.ct, 1, body_add=scalar * delta)
+        ct.degree += scalar
+
     def checked_scalar_add(self, ct, scalar: int):
         if not self.is_scalar_add_possible(ct, scalar):
             raise CheckError()

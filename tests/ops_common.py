@@ -167,6 +167,21 @@ def check_shortint_ops(cks, sks, device=False, tally=None):
         sks.checked_add(full, full)
     with pytest.raises(SI.CheckError):
         sks.checked_mul_lsb(full, b)
+    # the CRT flavour of scalar add scales by the KEY's moduli (scalar_add.rs:32-47): on a native-CRT
+    # ciphertext (modulus 3, carry 1) adding s moves the body by s/16 of half the torus
+    if not device:
+        crt = cks.encrypt_native_crt(2, 3)
+        before = crt.ct.copy()
+        sks.unchecked_scalar_add_assign_crt(crt, 5)
+        assert crt.degree == 2 + 5
+        delta = (1 << 63) // (sks.message_modulus * sks.carry_modulus)
+        assert int(crt.ct[-1]) == (int(before[-1]) + 5 * delta) % (1 << 64)
+        np.testing.assert_array_equal(crt.ct[:-1], before[:-1])
+        # create_trivial_assign: value reduced mod the message modulus, mask zero, n+1 words
+        # (server_side/mod.rs:284-310)
+        sks.create_trivial_assign(crt, 7)
+        assert crt.degree == 7 % msg and crt.ct.size == sks.parameters.lwe_dimension + 1
+        assert int(crt.ct[-1]) == (7 % msg) * delta and not crt.ct[:-1].any()
 
 
 def check_deferred_is_one_launch(cks, sks):
