@@ -23,6 +23,7 @@ import numpy as np
 
 from . import shortint as _si
 from .backend import CAMD_PBS_AUTO, Context
+from .integer_crt import CrtCiphertext, CrtClientKey, CrtClientOps, CrtServerOps  # noqa: F401
 from .shortint_ops import CheckError
 
 
@@ -45,8 +46,8 @@ class RadixCiphertext:
         return RadixCiphertext([b.to_host() for b in self.blocks])
 
 
-class ClientKey:
-    """client_key/mod.rs:25-93."""
+class ClientKey(CrtClientOps):
+    """client_key/mod.rs:25-93 (the CRT entry points, :279-431, come from ``CrtClientOps``)."""
 
     def __init__(self, parameters, seed: int = 0):
         self.key = _si.ClientKey(parameters, seed)
@@ -83,6 +84,32 @@ class ClientKey:
         ct = RadixCiphertext(blocks)
         return ct.to_device(device) if device is not None else ct
 
+    def encrypt_radix_without_padding(self, message: int, num_blocks: int) -> RadixCiphertext:
+        """client_key/mod.rs:136-160."""
+        return RadixCiphertext([self.key.encrypt_without_padding(d) for d in self._digits(message, num_blocks)])
+
+    def encrypt_one_block(self, message: int) -> _si.Ciphertext:
+        """client_key/mod.rs:184-186."""
+        return self.key.encrypt(message)
+
+    def decrypt_one_block(self, ct: _si.Ciphertext):
+        """client_key/mod.rs:191-193."""
+        return self.key.decrypt(ct)
+
+    def _recompose(self, vals, modulus: int, num_blocks: int):
+        whole = modulus ** num_blocks
+        if np.ndim(vals[0]) == 0:
+            return sum(int(v) * modulus ** i for i, v in enumerate(vals)) % (1 << 64) % whole
+        total = np.zeros(len(vals[0]), dtype=object)
+        for i, v in enumerate(vals):
+            total = total + v.astype(object) * (modulus ** i)
+        return np.array([int(t) % (1 << 64) % whole for t in total], dtype=np.uint64)
+
+    def decrypt_radix_without_padding(self, ctxt: RadixCiphertext):
+        """client_key/mod.rs:256-277."""
+        vals = [self.key.decrypt_message_and_carry_without_padding(b) for b in ctxt.blocks]
+        return self._recompose(vals, self.key.parameters.message_modulus, len(ctxt.blocks))
+
     def decrypt_radix(self, ctxt: RadixCiphertext):
         """client_key/mod.rs:215-234: blocks are decrypted with their carries and recombined."""
         modulus = self.key.parameters.message_modulus
@@ -113,8 +140,9 @@ class RadixClientKey(ClientKey):
         return self.decrypt_radix(ctxt)
 
 
-class ServerKey:
-    """server_key/mod.rs:24-68: a shortint server key whose max_degree leaves room for one carry."""
+class ServerKey(CrtServerOps):
+    """server_key/mod.rs:24-68: a shortint server key whose max_degree leaves room for one carry.
+    The radix operations are below; the CRT ones come from ``CrtServerOps``."""
 
     def __init__(self, key: _si.ServerKey):
         p = key.parameters
@@ -550,6 +578,44 @@ class ServerKey:
             self._full_propagate_many([lhs, rhs])
 
 
+def _install_remaining_forms() -> None:
+    """The assign / checked forms and ``*_parallelized`` names that differ from the methods above
+    only in where the result goes (radix/{neg,scalar_add,scalar_sub,scalar_mul,shift,mul}.rs and
+    their radix_parallel counterparts)."""
+    def checked_neg_assign(self, ctxt) -> None:
+        if not self.is_neg_possible(ctxt):
+            raise CheckError()
+        self.unchecked_neg_assign(ctxt)
+
+    def checked_scalar_add_assign(self, ct, scalar) -> None:
+        if not self.is_scalar_add_possible(ct, scalar):
+            raise CheckError()
+        self.unchecked_scalar_add_assign(ct, scalar)
+
+    def checked_scalar_sub_assign(self, ct, scalar) -> None:
+        if not self.is_scalar_sub_possible(ct, scalar):
+            raise CheckError()
+        self.unchecked_scalar_sub_assign(ct, scalar)
+
+    def checked_small_scalar_mul_assign(self, ct, scalar) -> None:
+        if not self.is_small_scalar_mul_possible(ct, scalar):
+            raise CheckError()
+        self.unchecked_small_scalar_mul_assign(ct, scalar)
+
+    def blockshift_right_assign(self, ctxt, shift) -> None:
+        """radix/shift.rs:48-50."""
+        ctxt.blocks = self.blockshift_right(ctxt, shift).blocks
+
+    for f in (checked_neg_assign, checked_scalar_add_assign, checked_scalar_sub_assign, checked_small_scalar_mul_assign,
+              blockshift_right_assign):
+        setattr(ServerKey, f.__name__, f)
+    for name in ("checked_small_scalar_mul", "checked_small_scalar_mul_assign", "smart_small_scalar_mul",
+                 "smart_small_scalar_mul_assign", "unchecked_small_scalar_mul", "unchecked_small_scalar_mul_assign",
+                 "smart_block_mul_assign", "smart_scalar_mul_assign", "unchecked_block_mul_assign", "unchecked_mul_assign",
+                 "unchecked_scalar_left_shift_assign", "unchecked_scalar_right_shift_assign"):
+        setattr(ServerKey, name + "_parallelized", getattr(ServerKey, name))
+
+
 def _install_bitwise() -> None:
     """unchecked_/checked_/smart_ bitand, bitor, bitxor (radix/bitwise_op.rs,
     radix_parallel/bitwise_op.rs): block-wise, all blocks in one launch."""
@@ -581,7 +647,13 @@ def _install_bitwise() -> None:
 
         setattr(ServerKey, f"unchecked_bit{name}", unchecked)
         setattr(ServerKey, f"unchecked_bit{name}_assign", unchecked_assign)
+        def checked_assign(self, lhs, rhs, _n=name) -> None:
+            if not self.is_functional_bivariate_pbs_possible(lhs, rhs):
+                raise CheckError()
+            self._blockwise(_n, lhs, rhs)
+
         setattr(ServerKey, f"checked_bit{name}", checked)
+        setattr(ServerKey, f"checked_bit{name}_assign", checked_assign)
         setattr(ServerKey, f"smart_bit{name}", smart)
         setattr(ServerKey, f"smart_bit{name}_assign", smart_assign)
         setattr(ServerKey, f"smart_bit{name}_parallelized", smart)
@@ -589,3 +661,4 @@ def _install_bitwise() -> None:
 
 
 _install_bitwise()
+_install_remaining_forms()

@@ -549,22 +549,41 @@ class ShortintOps:
         self.smart_mul_lsb_assign(res, rhs)
         return res
 
+    def _smart_mul_lsb_reductions(self, lhs, rhs) -> list:
+        """The operands that engine/server_side/mul.rs:121-156 reduces to their messages before
+        the product (the decision depends on degrees only, never on data)."""
+        if lhs.message_modulus > lhs.carry_modulus:
+            return [] if self.is_mul_small_carry_possible(lhs, rhs) else [lhs, rhs]
+        if self.is_mul_possible(lhs, rhs):
+            return []
+        full = rhs.carry_modulus * rhs.message_modulus - 1
+        if self.message_modulus * (rhs.degree + 1) < full:
+            return [lhs]
+        if (self.message_modulus + 1) + (lhs.degree + 1) < full:
+            return [rhs]
+        return [lhs, rhs]
+
+    def smart_mul_lsb_assign_many(self, pairs) -> None:
+        """smart_mul_lsb_assign on several independent (lhs, rhs) pairs: the reductions of all
+        pairs in one launch, then the products in another."""
+        pairs = list(pairs)
+        seen: set = set()
+        with self.deferred():
+            for lhs, rhs in pairs:
+                for c in self._smart_mul_lsb_reductions(lhs, rhs):
+                    if id(c) not in seen:   # an operand shared by several pairs is reduced once
+                        seen.add(id(c))
+                        self.message_extract_assign(c)
+        with self.deferred():
+            for lhs, rhs in pairs:
+                if lhs.message_modulus > lhs.carry_modulus:
+                    self.unchecked_mul_lsb_small_carry_assign(lhs, rhs)
+                else:
+                    self.unchecked_mul_lsb_assign(lhs, rhs)
+
     def smart_mul_lsb_assign(self, lhs, rhs) -> None:
         """engine/server_side/mul.rs:121-156."""
-        if lhs.message_modulus > lhs.carry_modulus:
-            if not self.is_mul_small_carry_possible(lhs, rhs):
-                self._extract_both(lhs, rhs)
-            self.unchecked_mul_lsb_small_carry_assign(lhs, rhs)
-        else:
-            if not self.is_mul_possible(lhs, rhs):
-                full = rhs.carry_modulus * rhs.message_modulus - 1
-                if self.message_modulus * (rhs.degree + 1) < full:
-                    self.message_extract_assign(lhs)
-                elif (self.message_modulus + 1) + (lhs.degree + 1) < full:
-                    self.message_extract_assign(rhs)
-                else:
-                    self._extract_both(lhs, rhs)
-            self.unchecked_mul_lsb_assign(lhs, rhs)
+        self.smart_mul_lsb_assign_many([(lhs, rhs)])
 
     def smart_mul_msb(self, lhs, rhs):
         res = lhs.clone()

@@ -261,3 +261,103 @@ def check_radix_ops(cks, sks, count=6, device=False, seed=3, num_blocks=4, tally
     two = icks.encrypt(77)
     if not device:
         assert icks.decrypt(isks.smart_mul(one, two)) == (201 * 77) % mod
+
+
+def make_basis(message_modulus: int):
+    """concrete-integer/src/server_key/crt/tests.rs:25-33."""
+    if message_modulus in (2, 3):
+        return [2]
+    if message_modulus < 8:
+        return [2, 3]
+    if message_modulus < 16:
+        return [2, 5, 7]
+    return [3, 7, 13]
+
+
+def check_crt_ops(cks, sks, count=6, device=False, seed=5, tally=None, rounds=6):
+    """The CRT tests of the reference (crt/tests.rs:35-273) on a batch that holds every residue
+    pair at least once; ``rounds`` stands for NB_TEST in the loops that feed a result back."""
+    t = tally or Tally()
+    icks = INT.ClientKey.from_shortint(cks)
+    isks = INT.ServerKey(sks)
+    basis = make_basis(sks.message_modulus)
+    mod = int(np.prod(basis))
+    rs = np.random.RandomState(seed)
+    x = rs.randint(0, mod, size=count).astype(np.uint64)
+    y = rs.randint(0, mod, size=count).astype(np.uint64)
+    x[0], y[0] = mod - 1, mod - 1
+    x[1], y[1] = 0, mod - 1
+    dev = "cuda" if device else None
+
+    def enc(v):
+        return icks.encrypt_crt_many(v, basis, device=dev)
+
+    def dec(ct):
+        return icks.decrypt_crt(ct)
+
+    t.eq(dec(enc(x)), x)
+    # unchecked mul
+    a = enc(x)
+    isks.unchecked_crt_mul_assign(a, enc(y))
+    t.eq(dec(a), (x * y) % mod)
+    # smart add, fed back
+    a, b, clear = enc(x), enc(y), x.copy()
+    for _ in range(rounds):
+        isks.smart_crt_add_assign(a, b)
+        clear = (clear + y) % mod
+        t.eq(dec(a), clear)
+    # smart mul, fed back (operands pick up degrees that force reductions)
+    a, b, clear = enc(x), enc(y), x.copy()
+    for _ in range(max(2, rounds // 2)):
+        isks.smart_crt_mul_assign(a, b)
+        clear = (clear * y) % mod
+        t.eq(dec(a), clear)
+    # smart neg, fed back
+    a, clear = enc(x), x.copy()
+    for _ in range(rounds):
+        isks.smart_crt_neg_assign(a)
+        clear = (mod - clear) % mod
+        t.eq(dec(a), clear)
+    # scalar add / mul on fresh ciphertexts, scalar sub fed back
+    for s in (0, 1, mod - 1, 1234567):
+        a = enc(x)
+        isks.smart_crt_scalar_add_assign(a, s)
+        t.eq(dec(a), (x + s) % mod)
+        a = enc(x)
+        isks.smart_crt_scalar_mul_assign(a, s)
+        t.eq(dec(a), (x * (s % mod)) % mod)
+    a, clear, s = enc(x), x.copy(), mod - 2
+    for _ in range(rounds):
+        isks.smart_crt_scalar_sub_assign(a, s)
+        clear = (clear + mod - s) % mod
+        t.eq(dec(a), clear)
+    # smart sub, fed back
+    a, b, clear = enc(x), enc(y), x.copy()
+    for _ in range(rounds):
+        isks.smart_crt_sub_assign(a, b)
+        clear = (clear + mod - y) % mod
+        t.eq(dec(a), clear)
+    # a function that commutes with the reductions (crt/mod.rs:44-65: x -> x*x)
+    a = enc(x)
+    isks.pbs_crt_compliant_function_assign(a, lambda v: v * v)
+    t.eq(dec(a), (x * x) % mod)
+    # checked forms and the value-returning forms leave their input alone
+    import pytest
+
+    a = enc(x)
+    r = isks.unchecked_crt_scalar_add(a, 1)
+    t.eq(dec(a), x)
+    t.eq(dec(r), (x + 1) % mod)
+    big = a
+    while isks.is_crt_add_possible(big, big):
+        big = isks.unchecked_crt_add(big, big)
+    with pytest.raises(SI.CheckError):
+        isks.checked_crt_scalar_mul(big, mod - 1)
+    # single integers use the same code (reference signatures); native CRT is client-side only
+    if not device:
+        one, two = icks.encrypt_crt(5 % mod, basis), icks.encrypt_crt(4 % mod, basis)
+        assert icks.decrypt_crt(isks.smart_crt_mul(one, two)) == (5 * 4) % mod
+        crt_key = INT.CrtClientKey.from_key(icks, basis)
+        assert crt_key.decrypt(crt_key.encrypt(mod - 1)) == mod - 1
+        native = icks.encrypt_native_crt(13 % mod, basis)
+        assert icks.decrypt_native_crt(native) == 13 % mod

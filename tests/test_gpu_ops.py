@@ -26,6 +26,13 @@ def test_radix_fheuint8(gpu_keys, device):
     OC.check_radix_ops(cks, sks, count=48, device=device, tally=OC.Tally(per_check=2, total=8))
 
 
+@pytest.mark.parametrize("device", [False, True])
+def test_crt_integers(gpu_keys, device):
+    """concrete-integer's CRT representation (basis [2, 3] for 2_2, crt/tests.rs:25-33)."""
+    cks, sks = gpu_keys
+    OC.check_crt_ops(cks, sks, count=48, device=device, rounds=10, tally=OC.Tally(per_check=2, total=8))
+
+
 def test_lwe_axpby_strided_views(gpu_ctx):
     """The leveled kernel against numpy, on strided block views of a [count][blocks][words] batch."""
     import torch

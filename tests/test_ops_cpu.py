@@ -31,6 +31,33 @@ def test_radix_layer_on_oracle():
     OC.check_radix_ops(cks, sks, count=5)
 
 
+def test_crt_layer_on_oracle():
+    cks, sks = OC.make_keys()
+    OC.check_crt_ops(cks, sks, count=5)
+
+
+def test_crt_operation_is_one_launch():
+    """The bootstraps of a CRT operation over all residues and all integers are one launch."""
+    from concrete_amd import integer as INT
+
+    cks, sks = OC.make_keys()
+    icks, isks = INT.ClientKey.from_shortint(cks), INT.ServerKey(sks)
+    a, b = icks.encrypt_crt_many([1, 2, 5], [2, 3]), icks.encrypt_crt_many([5, 4, 3], [2, 3])
+    before_l, before_b = sks.key.launches, sks.key.bootstraps
+    isks.unchecked_crt_mul_assign(a, b)
+    assert sks.key.launches == before_l + 1 and sks.key.bootstraps == before_b + 2 * 3
+    assert icks.decrypt_crt(a).tolist() == [5, 2, 3]
+
+
+def test_i_crt_matches_direct_search():
+    from concrete_amd.integer_crt import i_crt
+
+    for basis in ([2, 3], [2, 5, 7], [3, 7, 13], [2, 3, 5]):
+        whole = int(np.prod(basis))
+        for v in range(whole):
+            assert i_crt(basis, [v % m for m in basis]) == v
+
+
 def test_radix_multiplication_launch_count():
     """All 16 block products of a 4-block multiplication are one launch, whatever the batch."""
     from concrete_amd import integer as INT
