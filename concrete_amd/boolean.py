@@ -111,6 +111,10 @@ class ServerKey:
         sks.standard_bootstrap_key, sks.key_switching_key = bsk, ksk
         return sks
 
+    def trivial_encrypt(self, message: bool) -> Ciphertext:
+        """server_key/mod.rs:135-137."""
+        return Ciphertext(trivial=bool(message))
+
     # ---- helpers ----
     def _lwe_of(self, ct: Ciphertext) -> np.ndarray:
         """convert_into_lwe_ciphertext_32 (engine/mod.rs:196-215)."""

@@ -83,7 +83,7 @@ def test_boolean_gates_and_mux(gpu_ctx):
                 assert cks.decrypt(gate(cks.encrypt(x), y)) == f(x, y)
                 assert cks.decrypt(gate(x, cks.encrypt(y))) == f(x, y)
                 assert cks.decrypt(gate(Ciphertext(trivial=x), cks.encrypt(y))) == f(x, y)
-                assert gate(Ciphertext(trivial=x), Ciphertext(trivial=y)).trivial == f(x, y)
+                assert gate(sks.trivial_encrypt(x), Ciphertext(trivial=y)).trivial == f(x, y)
     for c in (False, True):
         for t in (False, True):
             for e in (False, True):
