@@ -14,7 +14,15 @@
 //
 // Tiling: one workgroup owns CT_TILE ciphertexts and 256 output columns; each key word fetched
 // (from L2 / Infinity Cache) is used CT_TILE times. Mask elements are decomposed once per chunk
-// into LDS, already converted to f64, and read back as broadcasts.
+// into LDS, already converted to f64.
+//
+// The digit operand of a product is the same for every lane (it belongs to the ciphertext, the
+// lanes are columns). Reading it from LDS as a broadcast costs a 16-byte LDS read per four
+// FMAs, and with sixteen waves per CU the LDS pipe, not the vector ALU, sets the pace (measured:
+// twice the FMA time). Instead one 8-byte read per key row puts the sixteen digits of the tile
+// into one register pair, lane l holding the digit of ciphertext l mod 16, and each FMA takes its
+// digit from there through the DPP row broadcast of the f64 pipe (row_newbcast:c hands lane c of
+// every 16-lane row to all lanes of that row): no further LDS traffic, no extra instruction.
 #include "kernels.hpp"
 
 namespace camd {
@@ -26,6 +34,32 @@ constexpr int KS_CT_TILE = 16;    // ciphertexts per workgroup
 constexpr int KS_COLS = 1;        // output columns per thread
 constexpr int KS_CHUNK = 32;      // mask elements decomposed per LDS refill
 constexpr int KS_MAX_LEVEL = 8;
+
+static_assert(KS_CT_TILE == 16, "the DPP row broadcast addresses one of 16 lanes: one tile = one row");
+
+// acc += digits[lane C of each row] * k. The DPP source must not have been written by one of the
+// two preceding vector instructions; ks_settle() below provides that distance once per key row.
+template <int C>
+__device__ __forceinline__ void fma_digit(double& acc, double digits16, double k) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc)
+      : "v"(digits16), "v"(k), "n"(C));
+}
+// Two idle issue slots, tied to the register pair the following products read through DPP, so
+// that whatever instruction produced that pair is at least two slots away from its first reader.
+__device__ __forceinline__ void ks_settle(double& digits16) { asm volatile("s_nop 1" : "+v"(digits16)); }
+
+template <int C, int COLS, int LIMBS>
+__device__ __forceinline__ void fma_tile(double (&part)[KS_CT_TILE][COLS][LIMBS], double digits16,
+                                         const double (&kf)[COLS][LIMBS]) {
+  if constexpr (C < KS_CT_TILE) {
+#pragma unroll
+    for (int q = 0; q < COLS; q++)
+#pragma unroll
+      for (int m = 0; m < LIMBS; m++) fma_digit<C>(part[C][q][m], digits16, kf[q][m]);
+    fma_tile<C + 1, COLS, LIMBS>(part, digits16, kf);
+  }
+}
 
 // exact integer-valued double (|v| < 2^52) -> two's-complement 64-bit word
 __device__ __forceinline__ uint64_t exact_to_u64(double v) {
@@ -71,60 +105,68 @@ __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
       }
   };
 
-  uint32_t chunk_no = 0;
+  // Key words travel two rows ahead of the products that use them, in two alternating register
+  // sets; the row index runs across the chunks (key rows are contiguous), so the pipeline never
+  // restarts. Columns past the end are clamped to the last one: those lanes compute a duplicate
+  // that is dropped at the store, and no load or product sits under a branch.
+  const uint32_t total_rows = in_dim * level;      // even: in_dim is a multiple of KS_CHUNK
+  const T* kcol[KS_COLS];
+#pragma unroll
+  for (int q = 0; q < KS_COLS; q++) kcol[q] = ksk + min(col_base + q * KS_THREADS + tid, ncols - 1);
+  auto fetch = [&](T (&kv)[KS_COLS], uint32_t row) {
+    const size_t off = (size_t)min(row, total_rows - 1) * ncols;
+#pragma unroll
+    for (int q = 0; q < KS_COLS; q++) kv[q] = kcol[q][off];
+  };
+  // a wave whose columns all lie past the end (the last column block is mostly empty: n+1 is
+  // rarely a multiple of the block) skips the products; it still takes part in the barriers
+  const bool wave_active = col_base + (tid & ~63u) < ncols;
+  T kva[KS_COLS], kvb[KS_COLS];
+  if (wave_active) {
+    fetch(kva, 0);
+    fetch(kvb, 1);
+  }
+  auto products = [&](T (&kv)[KS_COLS], uint32_t rr, uint32_t next_row) {
+    double kf[KS_COLS][LIMBS];
+#pragma unroll
+    for (int q = 0; q < KS_COLS; q++) {
+      kf[q][0] = (double)(uint32_t)kv[q];
+      if (LIMBS == 2) {
+        // opaque to the optimiser: it would otherwise widen this back into a 64-bit conversion
+        // (two conversions, a scale and an add) of a value it knows to be below 2^32
+        uint32_t hi = (uint32_t)((uint64_t)kv[q] >> 32);
+        asm("" : "+v"(hi));
+        kf[q][LIMBS - 1] = (double)hi;
+      }
+    }
+    fetch(kv, next_row);
+    // the sixteen digits of this key row, lane l holding ciphertext l mod 16
+    double digits16 = digits[(size_t)rr * KS_CT_TILE + (tid & (KS_CT_TILE - 1))];
+    ks_settle(digits16);
+    fma_tile<0, KS_COLS, LIMBS>(part, digits16, kf);
+  };
+
+  uint32_t chunk_no = 0, row_base = 0;
   for (uint32_t i0 = 0; i0 < in_dim; i0 += KS_CHUNK, chunk_no++) {
     // decompose KS_CHUNK mask elements of each ciphertext of the tile
     for (uint32_t e = tid; e < KS_CHUNK * KS_CT_TILE; e += KS_THREADS) {
       const uint32_t c = e % KS_CT_TILE, ii = e / KS_CT_TILE;
       const uint32_t i = i0 + ii;
       T a = 0;
-      if (i < in_dim && ct0 + c < count) a = ct_in[(ct0 + c) * in_stride + i];
+      if (ct0 + c < count) a = ct_in[(ct0 + c) * in_stride + i];
       T state = decomp_init_state<T>(a, base_log, level);
       for (uint32_t l = level; l >= 1; l--)
         digits[(ii * level + (l - 1)) * KS_CT_TILE + c] = (double)(int32_t)decomp_next<T>(state, base_log);
     }
     __syncthreads();
-    const uint32_t iend = min((uint32_t)KS_CHUNK, in_dim - i0);
-    const uint32_t rows = iend * level;               // key rows of this chunk, (i, l) flattened
-    const T* row0 = ksk + (size_t)i0 * level * ncols;
-    // key words are fetched one row ahead of the products that use them
-    T kv[KS_COLS];
-#pragma unroll
-    for (int q = 0; q < KS_COLS; q++) {
-      const uint32_t col = col_base + q * KS_THREADS + tid;
-      kv[q] = (col < ncols) ? row0[col] : T(0);
-    }
-    // a wave whose columns all lie past the end (the last column block is mostly empty: n+1 is
-    // rarely a multiple of the block) skips the products; it still takes part in the barriers
-    const bool wave_active = col_base + (tid & ~63u) < ncols;
-    for (uint32_t rr = 0; wave_active && rr < rows; rr++) {
-      double kf[KS_COLS][LIMBS];
-#pragma unroll
-      for (int q = 0; q < KS_COLS; q++) {
-        kf[q][0] = (double)(uint32_t)kv[q];
-        if (LIMBS == 2) kf[q][LIMBS - 1] = (double)(uint32_t)((uint64_t)kv[q] >> 32);
-      }
-      if (rr + 1 < rows) {
-        const T* nrow = row0 + (size_t)(rr + 1) * ncols;
-#pragma unroll
-        for (int q = 0; q < KS_COLS; q++) {
-          const uint32_t col = col_base + q * KS_THREADS + tid;
-          kv[q] = (col < ncols) ? nrow[col] : T(0);
-        }
-      }
-      const double2* dg = (const double2*)(digits + (size_t)rr * KS_CT_TILE);
-#pragma unroll
-      for (int c = 0; c < KS_CT_TILE; c += 2) {
-        const double2 d = dg[c >> 1];  // two ciphertexts' digits per LDS read
-#pragma unroll
-        for (int q = 0; q < KS_COLS; q++)
-#pragma unroll
-          for (int m = 0; m < LIMBS; m++) {
-            part[c][q][m] = fma(d.x, kf[q][m], part[c][q][m]);
-            part[c + 1][q][m] = fma(d.y, kf[q][m], part[c + 1][q][m]);
-          }
+    const uint32_t rows = KS_CHUNK * level;           // key rows of this chunk, (i, l) flattened
+    if (wave_active) {
+      for (uint32_t rr = 0; rr < rows; rr += 2) {
+        products(kva, rr, row_base + rr + 2);
+        products(kvb, rr + 1, row_base + rr + 3);
       }
     }
+    row_base += rows;
     __syncthreads();
     if ((chunk_no + 1) % flush_chunks == 0) flush();
   }
@@ -153,6 +195,8 @@ int launch_keyswitch(const T* ct_in, size_t in_stride, T* ct_out, size_t out_str
                      hipStream_t stream) {
   if (count == 0) return CAMD_OK;
   if (level > KS_MAX_LEVEL) return fail(CAMD_EINVAL, "keyswitch: level count above 8 is not supported");
+  if (in_dim == 0 || in_dim % KS_CHUNK != 0)
+    return fail(CAMD_EINVAL, "keyswitch: input dimension must be a positive multiple of 32");
   // number of products an f64 partial sum can take exactly: 2^(52 - 32 - (base_log - 1))
   const int budget_log = 52 - 32 - ((int)base_log - 1);
   if (budget_log < 0) return fail(CAMD_EINVAL, "keyswitch: base_log above 21 is not supported");

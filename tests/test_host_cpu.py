@@ -205,6 +205,40 @@ def test_wave_kernel_keeps_parked_key_registers_untouched(tmp_path):
     assert sorted(loads) == list(range(0, parked, 4))       # one load site per parked quad
 
 
+def test_keyswitch_dpp_operand_is_settled(tmp_path):
+    """The keyswitch products read their digit through a DPP row broadcast written in inline
+    assembly, where the compiler's hazard handling does not look: the broadcast source must not be
+    written by either of the two instructions issued before a product that reads it, and the
+    products must all be of the broadcast form. Checked on the generated code of both torus widths."""
+    import re
+    import subprocess
+
+    src = os.path.join(ROOT, "concrete_amd", "csrc", "keyswitch.hip")
+    out = tmp_path / "keyswitch.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src,
+                    "-o", str(out)], check=True, capture_output=True)
+    lines = [ln.strip() for ln in out.read_text().splitlines()]
+    code = [ln for ln in lines if ln and not ln.startswith((";", ".", "//")) and not ln.endswith(":")]
+    dpp = re.compile(r"v_fmac_f64_dpp v\[\d+:\d+\], v\[(\d+):(\d+)\], v\[\d+:\d+\] row_newbcast:(\d+) ")
+    seen = 0
+    for idx, ln in enumerate(code):
+        m = dpp.match(ln)
+        if not m:
+            continue
+        seen += 1
+        lo, hi = int(m.group(1)), int(m.group(2))
+        for prev in code[max(0, idx - 2):idx]:
+            if prev.startswith(("v_fmac_f64_dpp", "s_", "ds_read", "global_load")):
+                continue   # products write accumulators only; memory results are awaited by s_waitcnt
+            dest = re.match(r"v_\w+ v\[?(\d+)(?::(\d+))?\]?,", prev)
+            assert dest, prev
+            d_lo = int(dest.group(1))
+            d_hi = int(dest.group(2)) if dest.group(2) else d_lo
+            assert d_hi < lo or d_lo > hi, (prev, ln)
+    assert seen == 2 * 16 * 2 + 2 * 16, seen   # two rows x 16 ciphertexts x limbs, u64 and u32 kernels
+    assert "v_fma_f64" not in "\n".join(code) and "ds_read_b128" not in "\n".join(code)
+
+
 def test_headers_are_plain_c_and_the_c_driver_links():
     """include/*.h must be consumable by a C99 compiler (they are what a Rust `-sys` crate or a C
     host binds), and the plain-C driver used by the GPU test must link against the library."""
