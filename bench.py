@@ -32,7 +32,7 @@ from concrete_amd.shortint import ClientKey  # noqa: E402
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector peak (the FP64 matrix peak is the same figure)
 SEED = 0xC0FFEE
 CPU_SAMPLE = 4096                # ciphertexts timed on the host cores (about 10 s on 16 threads)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "pmc_per_dispatch_wave_v2_persistent.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "pmc_per_dispatch_final.json")
 
 
 def measured_traffic(kernel: str):
@@ -342,7 +342,7 @@ def main() -> None:
                 "frac": achieved / FP64_PEAK_TFLOPS,
                 "traffic": measured_traffic("wave_pbs_kernel") if dk.variant == 2 and count == 1 << 14 else None,
                 "traffic_unit": "bytes per launch past the L2 (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
-                                "profiles/r1/pmc_per_dispatch_wave_v2_persistent.json); the Fourier key is 56.7 MB",
+                                "profiles/r1/pmc_per_dispatch_final.json); the Fourier key is 56.7 MB",
                 "kernel": "programmable bootstrap (blind rotation), f64 on the vector ALUs",
                 "flop_per_bootstrap": fpp,
                 "kernel_ms": tm["pbs_ms"],
