@@ -237,6 +237,28 @@ __device__ __forceinline__ int32_t digit_next32(uint32_t& state) {
   }
 }
 
+// Single-level decomposition in one go: the signed digit of x. With state = the top BL bits of x
+// rounded to nearest, the digit is state for state <= B/2 and state - B above. Both the rounding
+// and the fold are additions below the extracted field, so they merge into one constant:
+//   ((hi + 2^(S-1) + (C << S)) >> S) mod B  ==  (state + C) mod B,   C = B/2 - 1,
+// and (state + C) mod B - C is state for state <= B/2 (no wrap) and state - B above (one wrap).
+// Three integer instructions and no condition register, against six and a compare.
+template <typename T, int BL>
+__device__ __forceinline__ int32_t digit_single32(T x) {
+  constexpr int BITS = Torus<T>::BITS;
+  constexpr int NON_REP = BITS - BL;
+  if constexpr (BITS == 64 && NON_REP >= 33) {
+    constexpr int S = NON_REP - 32;
+    constexpr uint32_t C = (1u << (BL - 1)) - 1u;
+    const uint32_t hi = (uint32_t)(x >> 32);
+    const uint32_t w = __builtin_amdgcn_ubfe(hi + ((1u << (S - 1)) + (C << S)), S, BL);
+    return (int32_t)w - (int32_t)C;
+  } else {
+    uint32_t st = digit_state32<T, BL, 1>(x);
+    return digit_next32<BL, 1>(st);
+  }
+}
+
 // broadcast lane 0's value through SGPRs so that the compiler sees a wave-uniform value
 __device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -687,9 +709,8 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
           const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - rot0[u & 1][t]) : rot0[u & 1][t];
           const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - rot1[u & 1][t]) : rot1[u & 1][t];
-          uint32_t s0 = digit_state32<T, BL, L>((T)(r0 - own0[u & 1][t]));
-          uint32_t s1 = digit_state32<T, BL, L>((T)(r1 - own1[u & 1][t]));
-          const int32_t g0 = digit_next32<BL, L>(s0), g1 = digit_next32<BL, L>(s1);
+          const int32_t g0 = digit_single32<T, BL>((T)(r0 - own0[u & 1][t]));
+          const int32_t g1 = digit_single32<T, BL>((T)(r1 - own1[u & 1][t]));
           x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), twg[u & 1][t]);
         }
       };
