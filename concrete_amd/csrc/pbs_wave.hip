@@ -702,16 +702,58 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           twg[u & 1][t] = tab[TAB_TWIST + j0];
         }
       };
+      // The 64-bit negation and subtraction are carry chains through a scalar register pair, and
+      // a vector instruction may not read such a pair within two issue slots of the instruction
+      // that wrote it: left to the compiler every chain costs an idle slot. Here the low halves
+      // of all eight coefficients of a unit are issued first, then the high halves.
       auto consume = [&](int u) {
+        if constexpr (sizeof(T) == 8) {
+          // r = wrapped ? -rot : rot, as (rot ^ m) - m with m = 0 or all ones (two's complement
+          // negation is complement plus one): no selects, one borrow chain
+          uint32_t msk[4][2], xhi[4][2], rlo[4][2];
+          bool rb[4][2];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-          const int q = 4 * (u & 1) + t;
-          const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-          const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - rot0[u & 1][t]) : rot0[u & 1][t];
-          const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - rot1[u & 1][t]) : rot1[u & 1][t];
-          const int32_t g0 = digit_single32<T, BL>((T)(r0 - own0[u & 1][t]));
-          const int32_t g1 = digit_single32<T, BL>((T)(r1 - own1[u & 1][t]));
-          x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), twg[u & 1][t]);
+          for (int t = 0; t < 4; t++) {
+            const uint32_t j0 = 64 * (4 * (u & 1) + t) + lane, j1 = j0 + M;
+            msk[t][0] = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(j0 - a_hat), LOGN, 1);
+            msk[t][1] = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(j1 - a_hat), LOGN, 1);
+            xhi[t][0] = (uint32_t)(rot0[u & 1][t] >> 32) ^ msk[t][0];
+            xhi[t][1] = (uint32_t)(rot1[u & 1][t] >> 32) ^ msk[t][1];
+            rb[t][0] = __builtin_sub_overflow((uint32_t)rot0[u & 1][t] ^ msk[t][0], msk[t][0], &rlo[t][0]);
+            rb[t][1] = __builtin_sub_overflow((uint32_t)rot1[u & 1][t] ^ msk[t][1], msk[t][1], &rlo[t][1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          uint32_t rhi[4][2];
+          bool db[4][2];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            rhi[t][0] = xhi[t][0] - msk[t][0] - (uint32_t)rb[t][0];
+            rhi[t][1] = xhi[t][1] - msk[t][1] - (uint32_t)rb[t][1];
+            // only the borrow of the low half of r - own is needed: the digit lies in the high dword
+            db[t][0] = rlo[t][0] < (uint32_t)own0[u & 1][t];
+            db[t][1] = rlo[t][1] < (uint32_t)own1[u & 1][t];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const int q = 4 * (u & 1) + t;
+            const uint32_t d0 = rhi[t][0] - (uint32_t)(own0[u & 1][t] >> 32) - (uint32_t)db[t][0];
+            const uint32_t d1 = rhi[t][1] - (uint32_t)(own1[u & 1][t] >> 32) - (uint32_t)db[t][1];
+            const int32_t g0 = digit_single32<T, BL>((T)d0 << 32);
+            const int32_t g1 = digit_single32<T, BL>((T)d1 << 32);
+            x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), twg[u & 1][t]);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const int q = 4 * (u & 1) + t;
+            const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+            const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - rot0[u & 1][t]) : rot0[u & 1][t];
+            const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - rot1[u & 1][t]) : rot1[u & 1][t];
+            const int32_t g0 = digit_single32<T, BL>((T)(r0 - own0[u & 1][t]));
+            const int32_t g1 = digit_single32<T, BL>((T)(r1 - own1[u & 1][t]));
+            x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), twg[u & 1][t]);
+          }
         }
       };
       issue(0);
