@@ -197,6 +197,29 @@ __device__ __forceinline__ uint64_t torus_accumulate(uint64_t acc, double t) {
   const uint32_t hi = q + (uint32_t)((__double2hiint(b) & 0xFFFFF) - 0x80000);
   return add_halves(acc, hi, lo);
 }
+// The same sum in two steps, so that a caller can separate the carry's producer from its
+// consumer. The second magic addition leaves b in [1.5*2^-12 - 2^-33, 1.5*2^-12 + 2^-33]: its
+// exponent field is constant, and (high dword of b & 0xFFFFF) - 0x80000 is the high dword minus
+// 0x3F380000; that constant is added together with the carry.
+struct TorusSum {
+  uint32_t lo, hi_partial;
+  bool carry;
+};
+__device__ __forceinline__ TorusSum torus_accumulate_low(uint64_t acc, double t) {
+  const double fr = t - rint(t);
+  const double a = fr + 0x1.8p20;
+  const uint32_t q = (uint32_t)__double2loint(a);
+  const double rem = fr - (a - 0x1.8p20);
+  const double b = rem + 0x1.8p-12;
+  TorusSum s;
+  s.carry = __builtin_add_overflow((uint32_t)acc, (uint32_t)__double2loint(b), &s.lo);
+  s.hi_partial = (uint32_t)(acc >> 32) + q + (uint32_t)__double2hiint(b);
+  return s;
+}
+__device__ __forceinline__ uint64_t torus_accumulate_high(const TorusSum& s) {
+  const uint32_t hi = s.hi_partial + 0xC0C80000u + (uint32_t)s.carry;  // -0x3F380000
+  return ((uint64_t)hi << 32) | s.lo;
+}
 __device__ __forceinline__ uint32_t torus_accumulate(uint32_t acc, double t) {
   const double fr = t - rint(t);
   return acc + (uint32_t)__double2loint(fr + 0x1.8p20);
@@ -877,12 +900,31 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
         if (c < 3) load_slot(3 + c);
         __builtin_amdgcn_sched_barrier(0);
         T* pc = ct0 + c * N;
+        if constexpr (sizeof(T) == 8) {
+          // low halves (and their carries) of all sixteen sums first, high halves afterwards: the
+          // carry registers are then read at a distance and cost no idle slots
+          TorusSum sum[8][2];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t j0 = 64 * q + lane;
-          const double2 v = cmul_conj(acc[c][q], twr[c & 1][q]);
-          pc[j0] = torus_accumulate(old0[c & 1][q], v.x);
-          pc[j0 + M] = torus_accumulate(old1[c & 1][q], v.y);
+          for (int q = 0; q < 8; q++) {
+            const double2 v = cmul_conj(acc[c][q], twr[c & 1][q]);
+            sum[q][0] = torus_accumulate_low(old0[c & 1][q], v.x);
+            sum[q][1] = torus_accumulate_low(old1[c & 1][q], v.y);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const uint32_t j0 = 64 * q + lane;
+            pc[j0] = torus_accumulate_high(sum[q][0]);
+            pc[j0 + M] = torus_accumulate_high(sum[q][1]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const uint32_t j0 = 64 * q + lane;
+            const double2 v = cmul_conj(acc[c][q], twr[c & 1][q]);
+            pc[j0] = torus_accumulate(old0[c & 1][q], v.x);
+            pc[j0 + M] = torus_accumulate(old1[c & 1][q], v.y);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
