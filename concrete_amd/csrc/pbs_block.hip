@@ -49,6 +49,35 @@ __device__ __forceinline__ void gst(void* base, uint32_t byte_off, V v) {
   *(V*)((char*)base + byte_off) = v;
 }
 
+// Signed decomposition on the high dword. When the decomposed field (base_log * level bits, plus
+// the rounding bit below it) lies in the upper 32 bits of a 64-bit torus word, the 64-bit variable
+// shifts of the generic form (two to four instructions each) are not needed. Both helpers return
+// exactly what decomp_init_state / decomp_next return; `hi` is the upper dword of the word.
+//   single level: digit = ((hi + 2^(S-1) + (C << S)) >> S) - C with C = B/2 - 1 and S = 32 - base_log:
+//   the rounding increment and the fold of the upper half of the digit range are both additions
+//   below the extracted field, so they merge into one constant (the field ends at bit 31, so the
+//   wrap of the 32-bit addition is the wrap modulo B).
+__device__ __forceinline__ int32_t block_digit_single(uint32_t hi, uint32_t bl) {
+  const uint32_t S = 32u - bl;
+  const uint32_t C = (1u << (bl - 1u)) - 1u;
+  const uint32_t K = (1u << (S - 1u)) + (C << S);   // wave-uniform: scalar instructions
+  return (int32_t)((hi + K) >> S) - (int32_t)C;
+}
+//   several levels: the state in 32 bits (base_log * level <= 31)
+__device__ __forceinline__ uint32_t block_state32(uint32_t hi, uint32_t bl, uint32_t levels) {
+  const uint32_t S = 32u - bl * levels;
+  return ((hi + (1u << (S - 1u))) >> S) & ((1u << (bl * levels)) - 1u);
+}
+__device__ __forceinline__ int32_t block_next32(uint32_t& state, uint32_t bl) {
+  const uint32_t mask = (1u << bl) - 1u;
+  const uint32_t res = state & mask;
+  state >>= bl;
+  uint32_t carry = ((res - 1u) | state) & res;
+  carry >>= (bl - 1u);
+  state += carry;
+  return (int32_t)(res - (carry << bl));
+}
+
 template <int PL>
 struct Blk {
   static constexpr int P = 1 << PL;
@@ -282,6 +311,8 @@ void block_pbs_kernel(PbsLaunch<T> a) {
     accg = (double2*)(my + (size_t)G * sizeof(T) + ST_BYTES);
   }
   const double inv_m = 1.0 / (double)M;
+  // the decomposed field and its rounding bit lie in the upper dword (all 64-bit sets do)
+  const bool high_dword = sizeof(T) == 8 && bl * L <= 31u;
 
   for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
     const T* in = a.ct_in + ct * a.in_stride;
@@ -349,15 +380,32 @@ void block_pbs_kernel(PbsLaunch<T> a) {
                 const uint32_t s0 = (j - a_rot) & (2 * N - 1), s1 = (j + M - a_rot) & (2 * N - 1);
                 const T x0 = ((s0 & N) ? (T)(T(0) - rot0[u]) : rot0[u]) - own0[u];
                 const T x1 = ((s1 & N) ? (T)(T(0) - rot1[u]) : rot1[u]) - own1[u];
-                T st0 = decomp_init_state<T>(x0, bl, L);
-                T st1 = decomp_init_state<T>(x1, bl, L);
-                const S g0 = decomp_next<T>(st0, bl);
-                const S g1 = decomp_next<T>(st1, bl);
-                if constexpr (L > 1) {
-                  gst<uint32_t>(str, ((uint32_t)(2 * q) * Tn + t) * 4u, (uint32_t)st0);
-                  gst<uint32_t>(str, ((uint32_t)(2 * q + 1) * Tn + t) * 4u, (uint32_t)st1);
+                if (high_dword) {
+                  // wave-uniform choice: every parameter set of the reference with a 64-bit torus
+                  const uint32_t h0 = (uint32_t)((uint64_t)x0 >> 32), h1 = (uint32_t)((uint64_t)x1 >> 32);
+                  int32_t g0, g1;
+                  if constexpr (L == 1) {
+                    g0 = block_digit_single(h0, bl);
+                    g1 = block_digit_single(h1, bl);
+                  } else {
+                    uint32_t st0 = block_state32(h0, bl, L), st1 = block_state32(h1, bl, L);
+                    g0 = block_next32(st0, bl);
+                    g1 = block_next32(st1, bl);
+                    gst<uint32_t>(str, ((uint32_t)(2 * q) * Tn + t) * 4u, st0);
+                    gst<uint32_t>(str, ((uint32_t)(2 * q + 1) * Tn + t) * 4u, st1);
+                  }
+                  x[q] = cmul(make_double2((double)g0, (double)g1), tw[u]);
+                } else {
+                  T st0 = decomp_init_state<T>(x0, bl, L);
+                  T st1 = decomp_init_state<T>(x1, bl, L);
+                  const S g0 = decomp_next<T>(st0, bl);
+                  const S g1 = decomp_next<T>(st1, bl);
+                  if constexpr (L > 1) {
+                    gst<uint32_t>(str, ((uint32_t)(2 * q) * Tn + t) * 4u, (uint32_t)st0);
+                    gst<uint32_t>(str, ((uint32_t)(2 * q + 1) * Tn + t) * 4u, (uint32_t)st1);
+                  }
+                  x[q] = cmul(make_double2(signed_to_double(g0), signed_to_double(g1)), tw[u]);
                 }
-                x[q] = cmul(make_double2(signed_to_double(g0), signed_to_double(g1)), tw[u]);
               }
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -376,14 +424,15 @@ void block_pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
               for (int u = 0; u < GS; u++) {
                 const int q = q0 + u;
-                T st0 = (T)sa[u], st1 = (T)sb[u];
-                const S g0 = decomp_next<T>(st0, bl);
-                const S g1 = decomp_next<T>(st1, bl);
+                // the parked state never exceeds 32 bits (base_log * (level - 1) + 1 bits)
+                uint32_t st0 = sa[u], st1 = sb[u];
+                const int32_t g0 = block_next32(st0, bl);
+                const int32_t g1 = block_next32(st1, bl);
                 if constexpr (L > 2) {  // with two levels the state is spent after this digit
-                  gst<uint32_t>(str, ((uint32_t)(2 * q) * Tn + t) * 4u, (uint32_t)st0);
-                  gst<uint32_t>(str, ((uint32_t)(2 * q + 1) * Tn + t) * 4u, (uint32_t)st1);
+                  gst<uint32_t>(str, ((uint32_t)(2 * q) * Tn + t) * 4u, st0);
+                  gst<uint32_t>(str, ((uint32_t)(2 * q + 1) * Tn + t) * 4u, st1);
                 }
-                x[q] = cmul(make_double2(signed_to_double(g0), signed_to_double(g1)), tw[u]);
+                x[q] = cmul(make_double2((double)g0, (double)g1), tw[u]);
               }
               __builtin_amdgcn_sched_barrier(0);
             }
