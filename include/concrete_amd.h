@@ -122,7 +122,8 @@ int camd_pbs_batch(camd_server_key* key, const void* ct_in, const uint32_t* lut_
                    size_t count);
 /* keyswitch only: replaces DefaultEngine::discard_keyswitch_lwe_ciphertext as called at
  * server_side/mod.rs:141-145 and Bootstrapper::keyswitch (bootstrapping/mod.rs:33-39).
- * ct_in: [count][kN+1]; ct_out: [count][n+1]. */
+ * ct_in: [count][kN+1]; ct_out: [count][n+1]. The input dimension kN must be a multiple of 32
+ * (it is for every polynomial size the library accepts). */
 int camd_ks_batch(camd_server_key* key, const void* ct_in, void* ct_out, size_t count);
 
 /* ---- device-pointer batch entry points (asynchronous on `stream`) ----
