@@ -38,17 +38,15 @@ constexpr int KS_MAX_LEVEL = 8;
 static_assert(KS_CT_TILE == 16, "the DPP row broadcast addresses one of 16 lanes: one tile = one row");
 
 // acc += digits[lane C of each row] * k. The DPP source must not have been written by one of the
-// two preceding vector instructions; ks_settle() below provides that distance once per key row.
+// two preceding vector instructions (a hazard the compiler does not track through inline
+// assembly). It never is here: the register pair comes straight from an LDS read, which is
+// awaited with s_waitcnt, not from the vector ALU; the CPU tests check this on the generated code.
 template <int C>
 __device__ __forceinline__ void fma_digit(double& acc, double digits16, double k) {
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
       : "+v"(acc)
       : "v"(digits16), "v"(k), "n"(C));
 }
-// Two idle issue slots, tied to the register pair the following products read through DPP, so
-// that whatever instruction produced that pair is at least two slots away from its first reader.
-__device__ __forceinline__ void ks_settle(double& digits16) { asm volatile("s_nop 1" : "+v"(digits16)); }
-
 template <int C, int COLS, int LIMBS>
 __device__ __forceinline__ void fma_tile(double (&part)[KS_CT_TILE][COLS][LIMBS], double digits16,
                                          const double (&kf)[COLS][LIMBS]) {
@@ -141,8 +139,7 @@ __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     }
     fetch(kv, next_row);
     // the sixteen digits of this key row, lane l holding ciphertext l mod 16
-    double digits16 = digits[(size_t)rr * KS_CT_TILE + (tid & (KS_CT_TILE - 1))];
-    ks_settle(digits16);
+    const double digits16 = digits[(size_t)rr * KS_CT_TILE + (tid & (KS_CT_TILE - 1))];
     fma_tile<0, KS_COLS, LIMBS>(part, digits16, kf);
   };
 
