@@ -134,7 +134,9 @@ int pick_variant(const camd_params& p, int requested, int* out) {
     return CAMD_OK;
   }
   if (requested != CAMD_PBS_AUTO) return fail(CAMD_EINVAL, "unknown pbs_variant");
-  *out = wave_supported(p) ? CAMD_PBS_WAVE : block_supported(p) ? CAMD_PBS_BLOCK : CAMD_PBS_GENERIC;
+  // AUTO takes the wave kernel where it is the default (its results agree with the bit-exact
+  // families at the decryption level, not bit for bit); other wave instances are opt-in
+  *out = wave_default(p) ? CAMD_PBS_WAVE : block_supported(p) ? CAMD_PBS_BLOCK : CAMD_PBS_GENERIC;
   return CAMD_OK;
 }
 

@@ -56,8 +56,10 @@ int block_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables,
 template <typename T>
 int block_launch_pbs(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream);
 
-// ---- wave-per-polynomial bootstrap for N in {512, 1024, 2048} (pbs_wave.hip) ----
-bool wave_supported(const camd_params& p);
+// ---- wave-per-ciphertext bootstrap: N = 1024 (64-bit, k = 2, one level) and N = 512 (32-bit, k = 2,
+// two levels) (pbs_wave.hip) ----
+bool wave_supported(const camd_params& p);   // an instance exists (CAMD_PBS_WAVE may be requested)
+bool wave_default(const camd_params& p);     // ... and CAMD_PBS_AUTO selects it
 size_t wave_tables_count(uint32_t N);
 size_t wave_scratch_bytes();   // arrival counters of the persistent waves, cleared by every launch
 void wave_fill_tables(uint32_t N, double2* host_tables);

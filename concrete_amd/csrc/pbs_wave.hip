@@ -1171,6 +1171,370 @@ void wave_pbs_kernel_v3(PbsLaunch<T> a) {
   }
 }
 
+// ================================================================================================
+// N = 512 instance (the boolean default parameters: 32-bit torus, k = 2, two levels, base 2^8).
+// Same schedule as wave_pbs_kernel_v2 — one wave per ciphertext, the transforms of a CMUX
+// interleaved as independent streams, the key rows of the next CMUX parked in accumulation
+// registers — with four points per lane: a 256-point transform is four radix-4 passes with three
+// exchanges, each a 4 x 4 transpose between the register index and one base-4 digit of the lane
+// index. With n = 64 a + lane, lane = 16 l2 + 4 l1 + l0 and f = k1 + 4 k2 + 16 k3 + 64 k4:
+//   pass 1 over a  (twiddle W_256^(lane k1)),      exchange register <-> l2,
+//   pass 2 over l2 (twiddle W_64^((lane & 15) k2)), exchange register <-> l1,
+//   pass 3 over l1 (twiddle W_16^((lane & 3) k3)),  exchange register <-> l0,
+//   pass 4 over l0; register k4 of lane 16 k1 + 4 k2 + k3 then holds X[f].
+// The inverse runs the mirror image (conjugate twiddles, same exchanges), unnormalised; the key
+// is pre-multiplied by 1/256. The exchange image is 4 rows of 64 values per plane, element
+// (r, lane) at r * 64 + (lane ^ (r << 2 * digit)): conflict-free for the lane groups of
+// ds_write_b64 and ds_read_b64 on both sides of every exchange (checked by enumeration).
+namespace w4 {
+constexpr int N = 512, M = 256, LOGN = 9, K = 2, R = 3, L = 2, BL = 8;
+constexpr int TAB_TWIST = 0;                 // [j] e^{+i pi j / N}, j < 256
+constexpr int TAB_A = 256;                   // [k-1][lane] W_256^(lane k), k = 1..3
+constexpr int TAB_B = TAB_A + 3 * 64;        // [k-1][m]    W_64^(m k),  m < 16
+constexpr int TAB_C = TAB_B + 3 * 16;        // [k-1][m]    W_16^(m k),  m < 4
+constexpr int TAB_COUNT = TAB_C + 3 * 4;
+constexpr int PLANE = 4 * 64;
+constexpr size_t slab_bytes() { return (size_t)R * N * sizeof(uint32_t) + 2 * PLANE * sizeof(double); }
+constexpr size_t lds_bytes() { return TAB_COUNT * sizeof(double2) + WAVES * slab_bytes(); }
+
+template <bool INV>
+__device__ __forceinline__ void dft4(double2 (&x)[4]) {
+  const double2 s0 = cadd(x[0], x[2]), d0 = csub(x[0], x[2]);
+  const double2 s1 = cadd(x[1], x[3]), d1 = csub(x[1], x[3]);
+  const double2 t = INV ? mul_pos_i(d1) : mul_neg_i(d1);
+  x[0] = cadd(s0, s1);
+  x[2] = csub(s0, s1);
+  x[1] = cadd(d0, t);
+  x[3] = csub(d0, t);
+}
+
+// transpose between the register index and base-4 digit DIGIT of the lane index, all streams
+template <int S, int DIGIT>
+__device__ __forceinline__ void exchange4(double2 (&x)[S][4], int lane, double* sre, double* sim) {
+  constexpr int SH = 2 * DIGIT;
+  const int d = (lane >> SH) & 3;
+  const int rest = lane & ~(3 << SH);
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int pos = r * 64 + (lane ^ (r << SH));
+      sre[pos] = x[s][r].x; sim[pos] = x[s][r].y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = d * 64 + (rest | ((j ^ d) << SH));
+      x[s][j] = make_double2(sre[idx], sim[idx]);
+    }
+  }
+}
+
+template <int S>
+__device__ __forceinline__ void fft256_forward_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
+                                                     double* sim) {
+  double2 w[3];
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_A + (k - 1) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    dft4<false>(x[s]);
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
+  }
+  exchange4<S, 2>(x, lane, sre, sim);
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_B + (k - 1) * 16 + (lane & 15)];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    dft4<false>(x[s]);
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
+  }
+  exchange4<S, 1>(x, lane, sre, sim);
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_C + (k - 1) * 4 + (lane & 3)];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    dft4<false>(x[s]);
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
+  }
+  exchange4<S, 0>(x, lane, sre, sim);
+#pragma unroll
+  for (int s = 0; s < S; s++) dft4<false>(x[s]);
+}
+
+template <int S>
+__device__ __forceinline__ void fft256_inverse_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
+                                                     double* sim) {
+  double2 w[3];
+#pragma unroll
+  for (int s = 0; s < S; s++) dft4<true>(x[s]);
+  exchange4<S, 0>(x, lane, sre, sim);
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_C + (k - 1) * 4 + (lane & 3)];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
+    dft4<true>(x[s]);
+  }
+  exchange4<S, 1>(x, lane, sre, sim);
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_B + (k - 1) * 16 + (lane & 15)];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
+    dft4<true>(x[s]);
+  }
+  exchange4<S, 2>(x, lane, sre, sim);
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_A + (k - 1) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
+    dft4<true>(x[s]);
+  }
+}
+
+// key conversion: one wave per polynomial, same transform, pre-scaled by 1/256
+__global__ __launch_bounds__(256) void bsk_fourier_kernel(const uint32_t* __restrict__ bsk, double2* __restrict__ out,
+                                                          const double2* __restrict__ tables, size_t polys) {
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = tables[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sre = (double*)(smem + TAB_COUNT * sizeof(double2)) + (size_t)wave * 2 * PLANE;
+  double* sim = sre + PLANE;
+  const size_t poly = (size_t)blockIdx.x * WAVES + wave;
+  if (poly >= polys) return;
+  const uint32_t* p = bsk + poly * N;
+  double2 x[1][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int j = 64 * a + lane;
+    const double re = (double)(int32_t)p[j] * (0x1.0p-32 / 256.0);
+    const double im = (double)(int32_t)p[j + M] * (0x1.0p-32 / 256.0);
+    x[0][a] = cmul(make_double2(re, im), tab[TAB_TWIST + j]);
+  }
+  fft256_forward_multi<1>(x, lane, tab, sre, sim);
+  double2* dst = out + poly * M;
+#pragma unroll
+  for (int g = 0; g < 4; g++) dst[g * 64 + lane] = x[0][g];
+}
+
+__device__ __forceinline__ int32_t next_digit(uint32_t& state) {
+  const uint32_t res = state & ((1u << BL) - 1u);
+  state >>= BL;
+  uint32_t carry = ((res - 1u) | state) & res;
+  carry >>= (BL - 1);
+  state += carry;
+  return (int32_t)(res - (carry << BL));
+}
+
+__global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<uint32_t> a) {
+  using T = uint32_t;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = a.tables[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * slab_bytes();
+  T* ct0 = (T*)slab;
+  double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
+  double* sim = sre + PLANE;
+  constexpr int S = R * L;          // forward streams: (level - 1) * R + row
+  constexpr int NS = S * R;         // key slabs per iteration: [level][row][col], 4 KiB each
+  constexpr int NA = 14;            // slabs parked in accumulation registers (224 AGPRs)
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  const size_t per_round = (size_t)gridDim.x * WAVES;
+  for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round) {
+    const T* in = a.ct_in + ct * a.in_stride;
+    const uint32_t n = a.n;
+    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
+    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N);
+    {
+      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+      for (int idx = lane; idx < R * N; idx += 64) {
+        const int c = idx >> LOGN, j = idx & (N - 1);
+        ct0[idx] = rotated_coeff<T>(lut + (size_t)c * N, j, d0, N);
+      }
+    }
+    uint32_t i = 0;
+    T a_cur = wave_uniform(in[0]);
+    while (i < n && a_cur == 0) {
+      i++;
+      a_cur = wave_uniform(in[i]);
+    }
+    v4u bqa[NA][4];
+#pragma unroll
+    for (int sl = 0; sl < NA; sl++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(bqa[sl][g].x));
+    bool work = false;
+    uint32_t a_hat = 0, cur = 0;
+    for (;;) {
+      double2 x[S][4];
+      v4u bqv[NS - NA][4];
+      if (work) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const T* p = ct0 + r * N;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+            const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
+            const T rot0 = p[s0 & (N - 1)], rot1 = p[s1 & (N - 1)];
+            const T r0 = (s0 & N) ? (T)(0u - rot0) : rot0;
+            const T r1 = (s1 & N) ? (T)(0u - rot1) : rot1;
+            uint32_t st0 = decomp_init_state<T>((T)(r0 - p[j0]), BL, L);
+            uint32_t st1 = decomp_init_state<T>((T)(r1 - p[j1]), BL, L);
+            const double2 tw = tab[TAB_TWIST + j0];
+#pragma unroll
+            for (int l = L; l >= 1; l--) {
+              const int32_t g0 = next_digit(st0), g1 = next_digit(st1);
+              x[(l - 1) * R + r][q] = cmul(make_double2((double)g0, (double)g1), tw);
+            }
+          }
+        }
+        // the slabs that do not fit the accumulation registers: requested now, needed after the transforms
+#pragma unroll
+        for (int sl = NA; sl < NS; sl++) {
+          const char* base = (const char*)(a.fbsk + (size_t)cur * NS * M) + (size_t)sl * (M * sizeof(double2)) + 2048;
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                         : "=v"(bqv[sl - NA][g])
+                         : "v"(lane_off), "s"(base), "n"(g * 1024 - 2048)
+                         : "memory");
+        }
+        fft256_forward_multi<S>(x, lane, tab, sre, sim);
+      }
+      double2 acc[R][4];
+      if (!work) {
+#pragma unroll
+        for (int c = 0; c < R; c++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) acc[c][g] = make_double2(0.0, 0.0);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int sl = 0; sl < NA; sl++)
+          asm volatile("" : "+a"(bqa[sl][0]), "+a"(bqa[sl][1]), "+a"(bqa[sl][2]), "+a"(bqa[sl][3]));
+#pragma unroll
+        for (int sl = NA; sl < NS; sl++)
+          asm volatile("" : "+v"(bqv[sl - NA][0]), "+v"(bqv[sl - NA][1]), "+v"(bqv[sl - NA][2]), "+v"(bqv[sl - NA][3]));
+        auto key = [&](int s, int c, int g) -> double2 {
+          const int sl = s * R + c;
+          return as_double2(sl < NA ? bqa[sl < NA ? sl : 0][g] : bqv[sl >= NA ? sl - NA : 0][g]);
+        };
+#pragma unroll
+        for (int c = 0; c < R; c++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            double2 v = cmul(key(0, c, g), x[0][g]);
+#pragma unroll
+            for (int s = 1; s < S; s++) v = cfma(key(s, c, g), x[s][g], v);
+            acc[c][g] = v;
+          }
+      }
+      // key rows of the next active iteration (index i), if any
+      const bool more = i < n;
+      const char* ggsw = (const char*)(a.fbsk + (size_t)(more ? i : 0) * NS * M);
+      if (more) {
+#pragma unroll
+        for (int sl = 0; sl < NA; sl++) {
+          const char* base = ggsw + (size_t)sl * (M * sizeof(double2)) + 2048;
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                         : "=a"(bqa[sl][g])
+                         : "v"(lane_off), "s"(base), "n"(g * 1024 - 2048)
+                         : "memory");
+        }
+      }
+      const uint32_t next_i = i;
+      const uint32_t next_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
+      if (more) {
+        i++;
+        a_cur = wave_uniform(in[i]);
+        while (i < n && a_cur == 0) {
+          i++;
+          a_cur = wave_uniform(in[i]);
+        }
+      }
+      fft256_inverse_multi<R>(acc, lane, tab, sre, sim);
+#pragma unroll
+      for (int c = 0; c < R; c++) {
+        T* pc = ct0 + c * N;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t j0 = 64 * q + lane;
+          const double2 v = cmul_conj(acc[c][q], tab[TAB_TWIST + j0]);
+          pc[j0] = torus_accumulate(pc[j0], v.x);
+          pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
+        }
+      }
+      if (!more) break;
+      work = true;
+      a_hat = next_hat;
+      cur = next_i;
+    }
+    T* out = a.ct_out + ct * a.out_stride;
+    for (int idx = lane; idx < K * N; idx += 64) {
+      const int c = idx >> LOGN, j = idx & (N - 1);
+      const T* p = ct0 + c * N;
+      out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
+    }
+    if (lane == 0) out[K * N] = ct0[K * N];
+  }
+}
+
+inline bool supported(const camd_params& p) {
+  return p.torus_bits == 32 && p.polynomial_size == 512 && p.glwe_dimension == 2 && p.pbs_level == 2 &&
+         p.pbs_base_log == 8;
+}
+
+inline void fill_tables(double2* t) {
+  for (int j = 0; j < 256; j++) {
+    const double ang = M_PI * (double)j / (double)N;
+    t[TAB_TWIST + j] = make_double2(std::cos(ang), std::sin(ang));
+  }
+  for (int k = 1; k < 4; k++) {
+    for (int m = 0; m < 64; m++) {
+      const double ang = -2.0 * M_PI * (double)(m * k) / 256.0;
+      t[TAB_A + (k - 1) * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+    for (int m = 0; m < 16; m++) {
+      const double ang = -2.0 * M_PI * (double)(m * k) / 64.0;
+      t[TAB_B + (k - 1) * 16 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+    for (int m = 0; m < 4; m++) {
+      const double ang = -2.0 * M_PI * (double)(m * k) / 16.0;
+      t[TAB_C + (k - 1) * 4 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+  }
+}
+
+inline int launch(const PbsLaunch<uint32_t>& a, hipStream_t stream) {
+  constexpr size_t lds = lds_bytes();
+  static_assert(lds <= 64 * 1024, "fits the default LDS limit");
+  int dev = 0, cus = 0;
+  CAMD_HIP(hipGetDevice(&dev));
+  CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
+  const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // one wave per SIMD (512 registers)
+  hipLaunchKernelGGL(pbs_kernel, dim3(persistent), dim3(256), lds, stream, a);
+  CAMD_HIP(hipGetLastError());
+  return CAMD_OK;
+}
+}  // namespace w4
+
 template <typename T, int K, int L, int BL>
 int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
   constexpr size_t lds = wave_lds_bytes<T, K>();
@@ -1226,15 +1590,20 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
 
 size_t wave_scratch_bytes() { return (size_t)SYNC_GROUPS * SYNC_STRIDE * sizeof(uint32_t); }
 
-bool wave_supported(const camd_params& p) {
-  if (p.polynomial_size != 1024) return false;
-  if (p.torus_bits == 64 && p.glwe_dimension == 2 && p.pbs_level == 1 && p.pbs_base_log == 23) return true;
-  return false;
+bool wave_default(const camd_params& p) {
+  return p.polynomial_size == 1024 && p.torus_bits == 64 && p.glwe_dimension == 2 && p.pbs_level == 1 &&
+         p.pbs_base_log == 23;
 }
 
-size_t wave_tables_count(uint32_t) { return TAB_COUNT; }
+bool wave_supported(const camd_params& p) { return wave_default(p) || w4::supported(p); }
+
+size_t wave_tables_count(uint32_t N) { return N == 512 ? (size_t)w4::TAB_COUNT : (size_t)TAB_COUNT; }
 
 void wave_fill_tables(uint32_t N, double2* t) {
+  if (N == 512) {
+    w4::fill_tables(t);
+    return;
+  }
   for (int j = 0; j < 512; j++) {
     const double ang = M_PI * (double)j / (double)N;
     t[TAB_TWIST + j] = make_double2(std::cos(ang), std::sin(ang));
@@ -1256,6 +1625,15 @@ int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, 
                         hipStream_t stream) {
   if (!wave_supported(p)) return fail(CAMD_EINVAL, "wave kernel: unsupported parameter set");
   const size_t polys = (size_t)p.lwe_dimension * p.pbs_level * (p.glwe_dimension + 1) * (p.glwe_dimension + 1);
+  if constexpr (sizeof(T) == 4) {
+    if (w4::supported(p)) {
+      const size_t lds4 = w4::TAB_COUNT * sizeof(double2) + WAVES * 2 * w4::PLANE * sizeof(double);
+      hipLaunchKernelGGL(w4::bsk_fourier_kernel, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds4, stream,
+                         bsk_std, fbsk, tables, polys);
+      CAMD_HIP(hipGetLastError());
+      return CAMD_OK;
+    }
+  }
   const size_t lds = TAB_COUNT * sizeof(double2) + WAVES * 2 * PLANE * sizeof(double);
   hipLaunchKernelGGL(wave_bsk_fourier_kernel<T>, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds, stream,
                      bsk_std, fbsk, tables, polys);
@@ -1268,6 +1646,8 @@ int wave_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
   if (a.count == 0) return CAMD_OK;
   if constexpr (sizeof(T) == 8) {
     if (a.N == 1024 && a.k == 2 && a.level == 1 && a.base_log == 23) return launch_instance<T, 2, 1, 23>(a, stream);
+  } else {
+    if (a.N == 512 && a.k == 2 && a.level == 2 && a.base_log == 8) return w4::launch(a, stream);
   }
   return fail(CAMD_EINVAL, "wave kernel: no instance for this parameter set");
 }

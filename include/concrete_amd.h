@@ -52,8 +52,12 @@ typedef struct camd_params {
   uint32_t torus_bits;
 } camd_params;
 
-/* Bootstrap kernel family. AUTO picks the wave-per-polynomial kernel when the parameter set
- * has one and the workgroup-per-ciphertext kernel otherwise. */
+/* Bootstrap kernel family. GENERIC and BLOCK produce ciphertexts that are bit for bit those of
+ * the CPU restatement of the reference algorithm; WAVE (one wavefront per ciphertext, the fastest
+ * where it has an instance) performs the same algorithm with its own order of f64 operations:
+ * decryptions and the noise bound are the same, the last bits of a ciphertext may differ. AUTO
+ * picks WAVE for the shortint sets with N = 1024 and BLOCK otherwise; the WAVE instance for the
+ * boolean default parameters (N = 512, 32-bit torus) is selected by asking for it. */
 #define CAMD_PBS_AUTO 0
 #define CAMD_PBS_GENERIC 1
 #define CAMD_PBS_WAVE 2

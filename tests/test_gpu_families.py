@@ -215,3 +215,43 @@ def test_plain_c_caller(gpu_ctx, tmp_path):
     got = np.fromfile(dst, dtype=np.uint64).reshape(cts.shape)
     want = o.ks_pbs_batch(ks.ksk, ks.fbsk, lut, None, cts, threads=4)
     assert np.array_equal(got, want)
+
+
+def test_boolean_wave_kernel_full_size(gpu_ctx):
+    """The wave-per-ciphertext instance for the boolean default parameters (asked for explicitly:
+    CAMD_PBS_AUTO keeps the bit-exact kernel for this set), full n = 586, against the oracle:
+    every decryption identical, every gate of the truth table right, and ciphertext words within
+    the last units of the 32-bit torus (same algorithm, different order of f64 operations)."""
+    p = P.DEFAULT_PARAMETERS
+    ks = get_keys(p, 32)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    assert dk.variant == CAMD_PBS_WAVE
+    acc = o.boolean_accumulator()
+    dk.upload_lut(acc)
+    T, F = 1 << 29, 7 << 29
+    rows, want_bits = [], []
+    for rep in range(8):
+        for a in (False, True):
+            for b in (False, True):
+                ca = o.lwe_encrypt(ks.rng, ks.small, T if a else F, p.lwe_modular_std_dev)
+                cb = o.lwe_encrypt(ks.rng, ks.small, T if b else F, p.lwe_modular_std_dev)
+                buf = (np.uint32(0) - (ca + cb)).astype(np.uint32)
+                buf[-1] = np.uint32((int(buf[-1]) + T) & 0xFFFFFFFF)
+                rows.append(buf)
+                want_bits.append(not (a and b))
+    cts = np.stack(rows)
+    want_big = np.stack([o.bootstrap(ks.fbsk, acc, c) for c in cts])
+    got_big = dk.pbs(cts)
+    diff = (got_big.astype(np.int64) - want_big.astype(np.int64) + (1 << 31)) % (1 << 32) - (1 << 31)
+    assert np.abs(diff).max() <= 2, np.abs(diff).max()
+    got = dk.pbs_ks(cts)
+    want = o.pbs_ks_batch(ks.ksk, ks.fbsk, acc, None, cts, threads=8)
+    for i, bit in enumerate(want_bits):
+        assert (o.lwe_phase(ks.small, got[i]) < (1 << 31)) == bit
+        assert (o.lwe_phase(ks.small, want[i]) < (1 << 31)) == bit
+    # ragged sizes around the persistent grid (more ciphertexts than one wave per SIMD of every CU)
+    many = np.tile(cts, (40, 1))[:1027]
+    out = dk.pbs_ks(many)
+    assert np.array_equal(out[:32], got) and np.array_equal(out[992:1024], got) and np.array_equal(out[1024:], got[:3])
+    dk.close()

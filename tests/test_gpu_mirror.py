@@ -129,3 +129,31 @@ def test_boolean_gate_batches_on_device(gpu_ctx):
         dev = sks.gate_batch(gate, da, db).cpu().numpy().view(np.uint32)
         assert np.array_equal(host, dev), gate
         assert np.array_equal(cks.decrypt_batch(dev), want), gate
+
+
+def test_boolean_gates_on_the_wave_kernel(gpu_ctx):
+    """Every gate's truth table, MUX and a device-resident gate batch with the wave-per-ciphertext
+    bootstrap selected explicitly for the default parameters."""
+    import torch
+
+    from concrete_amd import boolean as B
+    from concrete_amd.backend import CAMD_PBS_WAVE
+
+    cks = B.ClientKey(P.DEFAULT_PARAMETERS, seed=17)
+    sks = B.ServerKey.new(cks, ctx=gpu_ctx, variant=CAMD_PBS_WAVE)
+    assert sks.bootstrapper.key.variant == CAMD_PBS_WAVE
+    gates = {"and_": lambda x, y: x and y, "nand": lambda x, y: not (x and y), "or_": lambda x, y: x or y,
+             "nor": lambda x, y: not (x or y), "xor": lambda x, y: x != y, "xnor": lambda x, y: x == y}
+    for name, f in gates.items():
+        for x in (False, True):
+            for y in (False, True):
+                assert cks.decrypt(getattr(sks, name)(cks.encrypt(x), cks.encrypt(y))) == f(x, y), (name, x, y)
+    for c in (False, True):
+        assert cks.decrypt(sks.mux(cks.encrypt(c), cks.encrypt(True), cks.encrypt(False))) == c
+    rng = np.random.default_rng(3)
+    a_bits, b_bits = rng.integers(0, 2, 2000).astype(bool), rng.integers(0, 2, 2000).astype(bool)
+    a = torch.from_numpy(cks.encrypt_batch(a_bits).view(np.int32)).cuda()
+    b = torch.from_numpy(cks.encrypt_batch(b_bits).view(np.int32)).cuda()
+    out = sks.gate_batch("xor", a, b)
+    got = cks.decrypt_batch(out.cpu().numpy().view(np.uint32))
+    assert np.array_equal(got, a_bits ^ b_bits)
