@@ -1187,15 +1187,17 @@ void wave_pbs_kernel_v3(PbsLaunch<T> a) {
 // (r, lane) at r * 64 + (lane ^ (r << 2 * digit)): conflict-free for the lane groups of
 // ds_write_b64 and ds_read_b64 on both sides of every exchange (checked by enumeration).
 namespace w4 {
-constexpr int N = 512, M = 256, LOGN = 9, K = 2, R = 3, L = 2, BL = 8;
+constexpr int N = 512, M = 256, LOGN = 9;
 constexpr int TAB_TWIST = 0;                 // [j] e^{+i pi j / N}, j < 256
 constexpr int TAB_A = 256;                   // [k-1][lane] W_256^(lane k), k = 1..3
 constexpr int TAB_B = TAB_A + 3 * 64;        // [k-1][m]    W_64^(m k),  m < 16
 constexpr int TAB_C = TAB_B + 3 * 16;        // [k-1][m]    W_16^(m k),  m < 4
 constexpr int TAB_COUNT = TAB_C + 3 * 4;
 constexpr int PLANE = 4 * 64;
-constexpr size_t slab_bytes() { return (size_t)R * N * sizeof(uint32_t) + 2 * PLANE * sizeof(double); }
-constexpr size_t lds_bytes() { return TAB_COUNT * sizeof(double2) + WAVES * slab_bytes(); }
+template <typename T, int K>
+constexpr size_t slab_bytes() { return (size_t)(K + 1) * N * sizeof(T) + 2 * PLANE * sizeof(double); }
+template <typename T, int K>
+constexpr size_t lds_bytes() { return TAB_COUNT * sizeof(double2) + WAVES * slab_bytes<T, K>(); }
 
 template <bool INV>
 __device__ __forceinline__ void dft4(double2 (&x)[4]) {
@@ -1300,7 +1302,8 @@ __device__ __forceinline__ void fft256_inverse_multi(double2 (&x)[S][4], int lan
 }
 
 // key conversion: one wave per polynomial, same transform, pre-scaled by 1/256
-__global__ __launch_bounds__(256) void bsk_fourier_kernel(const uint32_t* __restrict__ bsk, double2* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void bsk_fourier_kernel(const T* __restrict__ bsk, double2* __restrict__ out,
                                                           const double2* __restrict__ tables, size_t polys) {
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
@@ -1311,13 +1314,15 @@ __global__ __launch_bounds__(256) void bsk_fourier_kernel(const uint32_t* __rest
   double* sim = sre + PLANE;
   const size_t poly = (size_t)blockIdx.x * WAVES + wave;
   if (poly >= polys) return;
-  const uint32_t* p = bsk + poly * N;
+  using SG = typename Torus<T>::Signed;
+  constexpr double SCALE = (sizeof(T) == 8 ? 0x1.0p-64 : 0x1.0p-32) / 256.0;
+  const T* p = bsk + poly * N;
   double2 x[1][4];
 #pragma unroll
   for (int a = 0; a < 4; a++) {
     const int j = 64 * a + lane;
-    const double re = (double)(int32_t)p[j] * (0x1.0p-32 / 256.0);
-    const double im = (double)(int32_t)p[j + M] * (0x1.0p-32 / 256.0);
+    const double re = signed_to_double((SG)p[j]) * SCALE;
+    const double im = signed_to_double((SG)p[j + M]) * SCALE;
     x[0][a] = cmul(make_double2(re, im), tab[TAB_TWIST + j]);
   }
   fft256_forward_multi<1>(x, lane, tab, sre, sim);
@@ -1326,6 +1331,7 @@ __global__ __launch_bounds__(256) void bsk_fourier_kernel(const uint32_t* __rest
   for (int g = 0; g < 4; g++) dst[g * 64 + lane] = x[0][g];
 }
 
+template <int BL>
 __device__ __forceinline__ int32_t next_digit(uint32_t& state) {
   const uint32_t res = state & ((1u << BL) - 1u);
   state >>= BL;
@@ -1335,21 +1341,22 @@ __device__ __forceinline__ int32_t next_digit(uint32_t& state) {
   return (int32_t)(res - (carry << BL));
 }
 
-__global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<uint32_t> a) {
-  using T = uint32_t;
+template <typename T, int K, int L, int BL>
+__global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
+  constexpr int R = K + 1;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
   for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = a.tables[t];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * slab_bytes();
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * slab_bytes<T, K>();
   T* ct0 = (T*)slab;
   double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
   double* sim = sre + PLANE;
   constexpr int S = R * L;          // forward streams: (level - 1) * R + row
   constexpr int NS = S * R;         // key slabs per iteration: [level][row][col], 4 KiB each
-  constexpr int NA = 14;            // slabs parked in accumulation registers (224 AGPRs)
+  constexpr int NA = NS < 14 ? NS : 14;   // slabs parked in accumulation registers (at most 224 AGPRs)
   const uint32_t lane_off = (uint32_t)lane * 16u;
   const size_t per_round = (size_t)gridDim.x * WAVES;
   for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round) {
@@ -1380,7 +1387,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<uint32_t> a) {
     uint32_t a_hat = 0, cur = 0;
     for (;;) {
       double2 x[S][4];
-      v4u bqv[NS - NA][4];
+      v4u bqv[NS - NA > 0 ? NS - NA : 1][4];
       if (work) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -1390,15 +1397,21 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<uint32_t> a) {
             const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
             const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
             const T rot0 = p[s0 & (N - 1)], rot1 = p[s1 & (N - 1)];
-            const T r0 = (s0 & N) ? (T)(0u - rot0) : rot0;
-            const T r1 = (s1 & N) ? (T)(0u - rot1) : rot1;
-            uint32_t st0 = decomp_init_state<T>((T)(r0 - p[j0]), BL, L);
-            uint32_t st1 = decomp_init_state<T>((T)(r1 - p[j1]), BL, L);
+            const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
+            const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
             const double2 tw = tab[TAB_TWIST + j0];
+            if constexpr (L == 1) {
+              const int32_t g0 = digit_single32<T, BL>((T)(r0 - p[j0]));
+              const int32_t g1 = digit_single32<T, BL>((T)(r1 - p[j1]));
+              x[r][q] = cmul(make_double2((double)g0, (double)g1), tw);
+            } else {
+              uint32_t st0 = digit_state32<T, BL, L>((T)(r0 - p[j0]));
+              uint32_t st1 = digit_state32<T, BL, L>((T)(r1 - p[j1]));
 #pragma unroll
-            for (int l = L; l >= 1; l--) {
-              const int32_t g0 = next_digit(st0), g1 = next_digit(st1);
-              x[(l - 1) * R + r][q] = cmul(make_double2((double)g0, (double)g1), tw);
+              for (int l = L; l >= 1; l--) {
+                const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
+                x[(l - 1) * R + r][q] = cmul(make_double2((double)g0, (double)g1), tw);
+              }
             }
           }
         }
@@ -1496,8 +1509,9 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<uint32_t> a) {
 }
 
 inline bool supported(const camd_params& p) {
-  return p.torus_bits == 32 && p.polynomial_size == 512 && p.glwe_dimension == 2 && p.pbs_level == 2 &&
-         p.pbs_base_log == 8;
+  if (p.polynomial_size != 512) return false;
+  if (p.torus_bits == 32) return p.glwe_dimension == 2 && p.pbs_level == 2 && p.pbs_base_log == 8;
+  return p.glwe_dimension == 3 && p.pbs_level == 1 && p.pbs_base_log == 18;   // the three small shortint sets
 }
 
 inline void fill_tables(double2* t) {
@@ -1521,15 +1535,18 @@ inline void fill_tables(double2* t) {
   }
 }
 
-inline int launch(const PbsLaunch<uint32_t>& a, hipStream_t stream) {
-  constexpr size_t lds = lds_bytes();
-  static_assert(lds <= 64 * 1024, "fits the default LDS limit");
+template <typename T, int K, int L, int BL>
+int launch(const PbsLaunch<T>& a, hipStream_t stream) {
+  constexpr size_t lds = lds_bytes<T, K>();
+  static_assert(lds <= 160 * 1024, "LDS budget exceeded");
+  auto kern = pbs_kernel<T, K, L, BL>;
+  if (lds > 64 * 1024) CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int dev = 0, cus = 0;
   CAMD_HIP(hipGetDevice(&dev));
   CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
   const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // one wave per SIMD (512 registers)
-  hipLaunchKernelGGL(pbs_kernel, dim3(persistent), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(persistent), dim3(256), lds, stream, a);
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;
 }
@@ -1625,14 +1642,13 @@ int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, 
                         hipStream_t stream) {
   if (!wave_supported(p)) return fail(CAMD_EINVAL, "wave kernel: unsupported parameter set");
   const size_t polys = (size_t)p.lwe_dimension * p.pbs_level * (p.glwe_dimension + 1) * (p.glwe_dimension + 1);
-  if constexpr (sizeof(T) == 4) {
-    if (w4::supported(p)) {
-      const size_t lds4 = w4::TAB_COUNT * sizeof(double2) + WAVES * 2 * w4::PLANE * sizeof(double);
-      hipLaunchKernelGGL(w4::bsk_fourier_kernel, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds4, stream,
-                         bsk_std, fbsk, tables, polys);
-      CAMD_HIP(hipGetLastError());
-      return CAMD_OK;
-    }
+  if (w4::supported(p)) {
+    if ((int)sizeof(T) * 8 != (int)p.torus_bits) return fail(CAMD_EINVAL, "wave kernel: torus width mismatch");
+    const size_t lds4 = w4::TAB_COUNT * sizeof(double2) + WAVES * 2 * w4::PLANE * sizeof(double);
+    hipLaunchKernelGGL(w4::bsk_fourier_kernel<T>, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds4, stream,
+                       bsk_std, fbsk, tables, polys);
+    CAMD_HIP(hipGetLastError());
+    return CAMD_OK;
   }
   const size_t lds = TAB_COUNT * sizeof(double2) + WAVES * 2 * PLANE * sizeof(double);
   hipLaunchKernelGGL(wave_bsk_fourier_kernel<T>, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds, stream,
@@ -1646,8 +1662,9 @@ int wave_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
   if (a.count == 0) return CAMD_OK;
   if constexpr (sizeof(T) == 8) {
     if (a.N == 1024 && a.k == 2 && a.level == 1 && a.base_log == 23) return launch_instance<T, 2, 1, 23>(a, stream);
+    if (a.N == 512 && a.k == 3 && a.level == 1 && a.base_log == 18) return w4::launch<T, 3, 1, 18>(a, stream);
   } else {
-    if (a.N == 512 && a.k == 2 && a.level == 2 && a.base_log == 8) return w4::launch(a, stream);
+    if (a.N == 512 && a.k == 2 && a.level == 2 && a.base_log == 8) return w4::launch<T, 2, 2, 8>(a, stream);
   }
   return fail(CAMD_EINVAL, "wave kernel: no instance for this parameter set");
 }

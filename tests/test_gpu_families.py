@@ -255,3 +255,38 @@ def test_boolean_wave_kernel_full_size(gpu_ctx):
     out = dk.pbs_ks(many)
     assert np.array_equal(out[:32], got) and np.array_equal(out[992:1024], got) and np.array_equal(out[1024:], got[:3])
     dk.close()
+
+
+@pytest.mark.parametrize("pname", ["PARAM_MESSAGE_1_CARRY_2", "PARAM_MESSAGE_2_CARRY_1", "PARAM_MESSAGE_3_CARRY_0"])
+def test_wave_kernel_small_shortint_sets(gpu_ctx, pname):
+    """The N = 512 wave instance on the three small shortint sets (64-bit torus, k = 3, one level),
+    selected explicitly, full n, against the oracle: every ciphertext decrypts to the same value as
+    the oracle's and to the table's value, for two look-up tables and every message; phase errors
+    stay far inside the decoding margin; batch sizes around the persistent grid give the same words."""
+    p = getattr(P, pname)
+    ks = get_keys(p, 64)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    assert dk.variant == CAMD_PBS_WAVE
+    space = p.message_modulus * p.carry_modulus
+    fs = [lambda x: x % p.message_modulus, lambda x: (3 * x + 1) % space]
+    luts = [o.generate_accumulator(f) for f in fs]
+    for l in luts:
+        dk.upload_lut(l)
+    count = 4 * space
+    msgs = np.arange(count) % space
+    ids = ((np.arange(count) // space) % 2).astype(np.uint32)
+    delta = O.shortint_delta(p)
+    cts = np.stack([o.lwe_encrypt(ks.rng, ks.glwe, int(m) * delta, p.lwe_modular_std_dev) for m in msgs])
+    got = dk.ks_pbs(cts, ids)
+    want = o.ks_pbs_batch(ks.ksk, ks.fbsk, np.concatenate(luts), ids, cts, threads=8)
+    for i in range(count):
+        expect = fs[ids[i]](int(msgs[i]))
+        pg, pw = o.lwe_phase(ks.glwe, got[i]), o.lwe_phase(ks.glwe, want[i])
+        assert O.shortint_decode(p, pg) == O.shortint_decode(p, pw) == expect
+        err = ((pg - expect * delta + 2 ** 63) % 2 ** 64 - 2 ** 63) / float(delta)
+        assert abs(err) < 0.25, err            # decoding fails at 0.5
+    many = np.tile(cts, (1100 // count + 1, 1))[:1027]
+    out = dk.ks_pbs(many, np.tile(ids, 1100 // count + 1)[:1027])
+    assert np.array_equal(out[:count], got) and np.array_equal(out[1027 - 3:], got[(1027 - 3) % count:(1027 - 3) % count + 3])
+    dk.close()

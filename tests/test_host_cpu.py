@@ -215,16 +215,18 @@ def test_wave512_kernel_keeps_parked_key_registers_untouched(tmp_path):
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src,
                     "-o", str(out)], check=True, capture_output=True)
     text = out.read_text()
-    start = text.index("w410pbs_kernel")
-    body = text[text.index(":", start):text.index("s_endpgm", start)]
-    assert "scratch_" not in body and "v_accvgpr_mov_b32" not in body
-    parked = 224
-    writes = [int(m.group(1)) for m in re.finditer(r"v_accvgpr_write_b32 a(\d+),", body)]
-    assert sorted(w for w in writes if w < parked) == list(range(0, parked, 4))
-    for m in re.finditer(r"ds_read\w* a\[(\d+):", body):
-        assert int(m.group(1)) >= parked
-    loads = [int(m.group(1)) for m in re.finditer(r"global_load_dwordx4 a\[(\d+):", body)]
-    assert sorted(loads) == list(range(0, parked, 4))
+    labels = [m.start() for m in re.finditer(r"^_ZN\S*w410pbs_kernel\S*:", text, re.M)]
+    assert len(labels) == 2          # the 32-bit two-level instance and the 64-bit single-level one
+    for start in labels:
+        body = text[text.index(":", start):text.index("s_endpgm", start)]
+        assert "scratch_" not in body and "v_accvgpr_mov_b32" not in body
+        parked = 224
+        writes = [int(m.group(1)) for m in re.finditer(r"v_accvgpr_write_b32 a(\d+),", body)]
+        assert sorted(w for w in writes if w < parked) == list(range(0, parked, 4))
+        for m in re.finditer(r"ds_read\w* a\[(\d+):", body):
+            assert int(m.group(1)) >= parked
+        loads = [int(m.group(1)) for m in re.finditer(r"global_load_dwordx4 a\[(\d+):", body)]
+        assert sorted(loads) == list(range(0, parked, 4))
 
 
 def test_keyswitch_dpp_operand_is_settled(tmp_path):
