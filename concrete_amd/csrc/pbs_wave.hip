@@ -1607,9 +1607,11 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
 
 size_t wave_scratch_bytes() { return (size_t)SYNC_GROUPS * SYNC_STRIDE * sizeof(uint32_t); }
 
+// the shortint instances (64-bit torus) are the default for their sets; the boolean one is opt-in
 bool wave_default(const camd_params& p) {
-  return p.polynomial_size == 1024 && p.torus_bits == 64 && p.glwe_dimension == 2 && p.pbs_level == 1 &&
-         p.pbs_base_log == 23;
+  if (p.torus_bits != 64) return false;
+  if (p.polynomial_size == 1024) return p.glwe_dimension == 2 && p.pbs_level == 1 && p.pbs_base_log == 23;
+  return w4::supported(p);
 }
 
 bool wave_supported(const camd_params& p) { return wave_default(p) || w4::supported(p); }

@@ -56,8 +56,9 @@ typedef struct camd_params {
  * the CPU restatement of the reference algorithm; WAVE (one wavefront per ciphertext, the fastest
  * where it has an instance) performs the same algorithm with its own order of f64 operations:
  * decryptions and the noise bound are the same, the last bits of a ciphertext may differ. AUTO
- * picks WAVE for the shortint sets with N = 1024 and BLOCK otherwise; the WAVE instance for the
- * boolean default parameters (N = 512, 32-bit torus) is selected by asking for it. */
+ * picks WAVE for the shortint sets that have an instance (N = 1024 with k = 2, N = 512 with k = 3)
+ * and BLOCK otherwise; the WAVE instance for the boolean default parameters (N = 512, 32-bit
+ * torus) is selected by asking for it. */
 #define CAMD_PBS_AUTO 0
 #define CAMD_PBS_GENERIC 1
 #define CAMD_PBS_WAVE 2
