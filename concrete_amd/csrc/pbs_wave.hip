@@ -1358,8 +1358,14 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
   constexpr int NS = S * R;         // key slabs per iteration: [level][row][col], 4 KiB each
   constexpr int NA = NS < 14 ? NS : 14;   // slabs parked in accumulation registers (at most 224 AGPRs)
   const uint32_t lane_off = (uint32_t)lane * 16u;
+  // persistent waves restart together per XCD (see wave_pbs_kernel_v2): key rows are then fetched
+  // into each L2 once instead of once per drifting wave
+  const uint32_t group = blockIdx.x % SYNC_GROUPS;
+  const uint32_t group_waves = ((gridDim.x - group + SYNC_GROUPS - 1) / SYNC_GROUPS) * WAVES;
+  uint32_t* arrivals = (uint32_t*)a.scratch + group * SYNC_STRIDE;
   const size_t per_round = (size_t)gridDim.x * WAVES;
-  for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round) {
+  uint32_t round = 0;
+  for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round, round++) {
     const T* in = a.ct_in + ct * a.in_stride;
     const uint32_t n = a.n;
     const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
@@ -1505,6 +1511,17 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
       out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
     }
     if (lane == 0) out[K * N] = ct0[K * N];
+    if ((size_t)(round + 1) * per_round < a.count) {
+      if (lane == 0) {
+        __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t target = (round + 1) * group_waves - group_waves / WAVE_QUORUM_SLACK;
+        for (uint32_t spin = 0; spin < (1u << 16); spin++) {
+          if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+          __builtin_amdgcn_s_sleep(16);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -1546,6 +1563,10 @@ int launch(const PbsLaunch<T>& a, hipStream_t stream) {
   CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
   const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // one wave per SIMD (512 registers)
+  if (persistent < grid) {
+    if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
+    CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
+  }
   hipLaunchKernelGGL(kern, dim3(persistent), dim3(256), lds, stream, a);
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;

@@ -6,7 +6,7 @@ P=$1; CNT=$2; TAG=$3; shift 3
 OUT=$ROOT/gpurun_out/pmcc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc "$@" -d $OUT/a -o pmc -- python3 $ROOT/scripts/family_bench.py $P $CNT 1 > $OUT/a.log 2>&1 || { echo pass failed; tail -5 $OUT/a.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc "$@" -d $OUT/a -o pmc -- python3 $ROOT/scripts/family_bench.py $P $CNT 1 ${CAMD_VARIANT:-0} > $OUT/a.log 2>&1 || { echo pass failed; tail -5 $OUT/a.log; exit 1; }
 find $OUT -type f \( -name "*.db" -o -name "*.json" \) -delete
 python3 - $OUT <<'PY'
 import csv,glob,sys,collections
