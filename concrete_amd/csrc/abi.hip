@@ -1,6 +1,9 @@
 // C ABI of the backend: contexts, server keys, look-up tables, batch entry points.
 // The header (include/concrete_amd.h) documents which reference interface each entry replaces.
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -22,7 +25,9 @@ using namespace camd;
 
 struct camd_context {
   int device = 0;
-  hipStream_t stream = nullptr;  // used by the host-pointer entry points
+  hipStream_t stream = nullptr;    // kernels of the host-pointer entry points
+  hipStream_t copy_in = nullptr;   // their host -> device copies
+  hipStream_t copy_out = nullptr;  // their device -> host copies
 };
 
 namespace {
@@ -320,34 +325,100 @@ int dispatch_device(camd_server_key* key, Op op, const void* in, const uint32_t*
                                  : run_op_device<uint32_t>(key, op, in, ids, out, count, s);
 }
 
+// Ciphertexts per slice of a host-buffer batch: the copies of one slice run beside the kernels
+// of its neighbours. CAMD_HOST_CHUNK overrides it (0 = never slice).
+size_t host_chunk() {
+  const char* e = std::getenv("CAMD_HOST_CHUNK");
+  if (!e || !*e) return 2048;
+  const long v = std::strtol(e, nullptr, 10);
+  return v <= 0 ? SIZE_MAX : (size_t)v;
+}
+
+struct EventList {
+  std::vector<hipEvent_t> ev;
+  hipError_t add(hipEvent_t* out) {
+    hipError_t e = hipEventCreateWithFlags(out, hipEventDisableTiming);
+    if (e == hipSuccess) ev.push_back(*out);
+    return e;
+  }
+  ~EventList() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+};
+
+template <typename T>
+int run_op_host(camd_server_key* key, Op op, const void* in, const uint32_t* d_ids, void* out, size_t count) {
+  camd_context* ctx = key->ctx;
+  const size_t iw = in_words(key, op) * key->word, ow = out_words(key, op) * key->word;
+  const size_t chunk = host_chunk();
+  // a short tail is folded into the slice before it
+  const size_t slices = count / 2 < chunk ? 1 : count / chunk;
+  EventList events;
+  hipEvent_t computed_prev = nullptr;
+  size_t prev_first = 0, prev_n = 0;
+  int rc = CAMD_OK;
+  hipError_t e = hipSuccess;
+  for (size_t i = 0; i < slices && rc == CAMD_OK && e == hipSuccess; i++) {
+    const size_t first = i * chunk, n = (i + 1 == slices) ? count - first : chunk;
+    hipEvent_t arrived = nullptr, computed = nullptr;
+    e = events.add(&arrived);
+    if (e == hipSuccess) e = events.add(&computed);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync((char*)key->stage_in.ptr + first * iw, (const char*)in + first * iw, n * iw, hipMemcpyHostToDevice,
+                         ctx->copy_in);
+    if (e == hipSuccess) e = hipEventRecord(arrived, ctx->copy_in);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, arrived, 0);
+    if (e != hipSuccess) break;
+    rc = run_op_device<T>(key, op, (char*)key->stage_in.ptr + first * iw, d_ids ? d_ids + first : nullptr,
+                          (char*)key->stage_out.ptr + first * ow, n, ctx->stream);
+    if (rc != CAMD_OK) break;
+    e = hipEventRecord(computed, ctx->stream);
+    // the previous slice goes home while this one computes
+    if (e == hipSuccess && computed_prev) {
+      e = hipStreamWaitEvent(ctx->copy_out, computed_prev, 0);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync((char*)out + prev_first * ow, (char*)key->stage_out.ptr + prev_first * ow, prev_n * ow,
+                           hipMemcpyDeviceToHost, ctx->copy_out);
+    }
+    computed_prev = computed; prev_first = first; prev_n = n;
+  }
+  if (rc == CAMD_OK && e == hipSuccess) {
+    e = hipStreamWaitEvent(ctx->copy_out, computed_prev, 0);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync((char*)out + prev_first * ow, (char*)key->stage_out.ptr + prev_first * ow, prev_n * ow,
+                         hipMemcpyDeviceToHost, ctx->copy_out);
+  }
+  // nothing of this call may be in flight when it returns, whatever happened
+  const hipError_t e1 = hipStreamSynchronize(ctx->copy_in);
+  const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  const hipError_t e3 = hipStreamSynchronize(ctx->copy_out);
+  if (rc != CAMD_OK) return rc;
+  for (hipError_t x : {e, e1, e2, e3})
+    if (x != hipSuccess) return fail(CAMD_EHIP, std::string("host-buffer batch: ") + hipGetErrorString(x));
+  return CAMD_OK;
+}
+
 int dispatch_host(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count) {
   if (!key || (!in && count) || (!out && count)) return fail(CAMD_EINVAL, "null argument");
   if (count == 0) return CAMD_OK;
   std::lock_guard<std::mutex> lock(key->mu);
   DeviceGuard g(key->ctx->device);
   if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
-  hipStream_t s = key->ctx->stream;
   const size_t ib = count * in_words(key, op) * key->word, ob = count * out_words(key, op) * key->word;
   int rc = key->stage_in.ensure(ib);
   if (rc == CAMD_OK) rc = key->stage_out.ensure(ob);
   if (rc == CAMD_OK && ids) rc = key->stage_ids.ensure(count * sizeof(uint32_t));
+  // scratch is sized once, for the whole batch, before any slice is in flight
+  if (rc == CAMD_OK) rc = reserve_locked(key, count);
   if (rc != CAMD_OK) return rc;
   if (ids) {
     for (size_t i = 0; i < count; i++)
       if (ids[i] >= key->lut_count) return fail(CAMD_EINVAL, "lut id out of range");
-    CAMD_HIP(hipMemcpyAsync(key->stage_ids.ptr, ids, count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    CAMD_HIP(hipMemcpyAsync(key->stage_ids.ptr, ids, count * sizeof(uint32_t), hipMemcpyHostToDevice, key->ctx->stream));
   }
-  CAMD_HIP(hipMemcpyAsync(key->stage_in.ptr, in, ib, hipMemcpyHostToDevice, s));
   const uint32_t* d_ids = ids ? (const uint32_t*)key->stage_ids.ptr : nullptr;
-  rc = key->p.torus_bits == 64 ? run_op_device<uint64_t>(key, op, key->stage_in.ptr, d_ids, key->stage_out.ptr, count, s)
-                               : run_op_device<uint32_t>(key, op, key->stage_in.ptr, d_ids, key->stage_out.ptr, count, s);
-  if (rc != CAMD_OK) {
-    (void)hipStreamSynchronize(s);
-    return rc;
-  }
-  CAMD_HIP(hipMemcpyAsync(out, key->stage_out.ptr, ob, hipMemcpyDeviceToHost, s));
-  CAMD_HIP(hipStreamSynchronize(s));
-  return CAMD_OK;
+  return key->p.torus_bits == 64 ? run_op_host<uint64_t>(key, op, in, d_ids, out, count)
+                                 : run_op_host<uint32_t>(key, op, in, d_ids, out, count);
 }
 
 }  // namespace
@@ -374,7 +445,11 @@ int camd_context_create(int device_id, camd_context** out) {
   if (!ctx) return fail(CAMD_ENOMEM, "out of host memory");
   ctx->device = device_id;
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking);
   if (e != hipSuccess) {
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
     delete ctx;
     return fail(CAMD_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   }
@@ -386,6 +461,8 @@ int camd_context_destroy(camd_context* ctx) {
   if (!ctx) return CAMD_OK;
   DeviceGuard g(ctx->device);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
+  if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
   delete ctx;
   return CAMD_OK;
 }

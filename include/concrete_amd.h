@@ -10,7 +10,10 @@
  *     throws, aborts or prints. camd_last_error() returns the calling thread's last message.
  *   - "host" entry points take host pointers (pageable or pinned), block until the result is
  *     in the output buffer, and may be called concurrently on one key (calls are serialised
- *     per key). "device" entry points take device pointers on the key's GPU plus a
+ *     per key). A large host batch is cut into slices of 2048 ciphertexts (environment
+ *     variable CAMD_HOST_CHUNK, 0 = one slice) so that the PCIe copies of one slice run
+ *     beside the kernels of its neighbours; results do not depend on the slicing.
+ *     "device" entry points take device pointers on the key's GPU plus a
  *     hipStream_t (as void*, NULL = the default stream), enqueue the kernels and return
  *     without synchronising.
  *   - LWE ciphertexts are dim+1 torus words, body last. GLWE ciphertexts (look-up tables) are

@@ -207,6 +207,38 @@ def test_wave_persistent_rounds_and_tail(gpu_ctx, keys_2_2):
     assert np.count_nonzero(dec(got) != (3 * msgs) % 4) <= 3   # the parameter set's own failure rate
 
 
+@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC, CAMD_PBS_WAVE])
+def test_host_buffer_batch_is_sliced_without_changing_results(gpu_ctx, keys_2_2, variant, monkeypatch):
+    """A host-buffer batch is cut into slices whose copies overlap the kernels of their
+    neighbours. Word for word the same output as one launch over device-resident inputs,
+    including the per-ciphertext table ids and a ragged last slice."""
+    import torch
+
+    ks = keys_2_2
+    dk = make_device_key(gpu_ctx, ks, variant)
+    luts = [ks.o.generate_accumulator(f) for f in (lambda x: x % 4, lambda x: x // 4)]
+    for l in luts:
+        dk.upload_lut(l)
+    count = 3 * 16 + 5
+    cts = encrypt_batch(ks, np.arange(count) % 16)
+    lut_ids = (np.arange(count) % 2).astype(np.uint32)
+
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    d_ids = torch.from_numpy(lut_ids.view(np.int32)).cuda()
+    d_out = torch.empty_like(d_in)
+    dk.ks_pbs_device(d_in, d_ids, d_out, count, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    whole = d_out.cpu().numpy().view(np.uint64)
+
+    monkeypatch.setenv("CAMD_HOST_CHUNK", "16")      # 3 slices: 16, 16, 21
+    sliced = dk.ks_pbs(cts, lut_ids)
+    monkeypatch.setenv("CAMD_HOST_CHUNK", "0")       # one slice
+    single = dk.ks_pbs(cts, lut_ids)
+    assert np.array_equal(sliced, whole) and np.array_equal(single, whole)
+    monkeypatch.setenv("CAMD_HOST_CHUNK", "16")
+    assert np.array_equal(dk.ks(cts), np.stack([ks.o.keyswitch(ks.ksk, c) for c in cts]))
+
+
 def test_other_wave_schedules_in_their_own_process():
     """The schedule of the wave family is chosen once per process (CAMD_WAVE_SCHEDULE); the first
     (one row at a time) and third (two waves per SIMD) schedules are kept as selectable variants and
