@@ -23,6 +23,8 @@
 // into one register pair, lane l holding the digit of ciphertext l mod 16, and each FMA takes its
 // digit from there through the DPP row broadcast of the f64 pipe (row_newbcast:c hands lane c of
 // every 16-lane row to all lanes of that row): no further LDS traffic, no extra instruction.
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace camd {
@@ -70,7 +72,7 @@ template <typename T>
 __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void keyswitch_kernel(
     const T* __restrict__ ct_in, size_t in_stride, T* __restrict__ ct_out, size_t out_stride,
     const T* __restrict__ ksk, uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level,
-    size_t count, uint32_t flush_chunks) {
+    size_t count, uint32_t flush_chunks, uint32_t chunks_per_split) {
   constexpr int LIMBS = sizeof(T) / 4;
   extern __shared__ double digits[];  // [KS_CHUNK][level][KS_CT_TILE]
 
@@ -119,10 +121,15 @@ __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
   // a wave whose columns all lie past the end (the last column block is mostly empty: n+1 is
   // rarely a multiple of the block) skips the products; it still takes part in the barriers
   const bool wave_active = col_base + (tid & ~63u) < ncols;
+  // blockIdx.z selects a contiguous range of chunks (a small batch is split over the key rows
+  // so that it still fills the chip); the ranges' sums meet in the output through atomic adds
+  const uint32_t chunk_first = blockIdx.z * chunks_per_split;
+  const uint32_t chunk_end = min(chunk_first + chunks_per_split, in_dim / KS_CHUNK);
+  uint32_t chunk_no = 0, row_base = chunk_first * KS_CHUNK * level;
   T kva[KS_COLS], kvb[KS_COLS];
   if (wave_active) {
-    fetch(kva, 0);
-    fetch(kvb, 1);
+    fetch(kva, row_base);
+    fetch(kvb, row_base + 1);
   }
   auto products = [&](T (&kv)[KS_COLS], uint32_t rr, uint32_t next_row) {
     double kf[KS_COLS][LIMBS];
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     fma_tile<0, KS_COLS, LIMBS>(part, digits16, kf);
   };
 
-  uint32_t chunk_no = 0, row_base = 0;
-  for (uint32_t i0 = 0; i0 < in_dim; i0 += KS_CHUNK, chunk_no++) {
+  for (uint32_t chunk = chunk_first; chunk < chunk_end; chunk++, chunk_no++) {
+    const uint32_t i0 = chunk * KS_CHUNK;
     // decompose KS_CHUNK mask elements of each ciphertext of the tile
     for (uint32_t e = tid; e < KS_CHUNK * KS_CT_TILE; e += KS_THREADS) {
       const uint32_t c = e % KS_CT_TILE, ii = e / KS_CT_TILE;
@@ -177,11 +184,30 @@ __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
       const uint32_t col = col_base + q * KS_THREADS + tid;
       if (col < ncols) {
         T v = total[c][q];
-        if (col == out_dim) v += ct_in[(ct0 + c) * in_stride + in_dim];
-        ct_out[(ct0 + c) * out_stride + col] = v;
+        T* dst = &ct_out[(ct0 + c) * out_stride + col];
+        if (gridDim.z > 1) {
+          // the output was preset to (0, ..., 0, b_in); wrapping integer sums commute, so the
+          // result does not depend on the order in which the ranges arrive
+          if constexpr (sizeof(T) == 8) atomicAdd((unsigned long long*)dst, (unsigned long long)v);
+          else atomicAdd((unsigned int*)dst, (unsigned int)v);
+        } else {
+          if (col == out_dim) v += ct_in[(ct0 + c) * in_stride + in_dim];
+          *dst = v;
+        }
       }
     }
   }
+}
+
+// out = (0, ..., 0, b_in): the start value of a keyswitch whose key rows are split over blocks
+template <typename T>
+__global__ __launch_bounds__(256) void keyswitch_preset_kernel(const T* __restrict__ ct_in, size_t in_stride,
+                                                               T* __restrict__ ct_out, size_t out_stride,
+                                                               uint32_t in_dim, uint32_t out_dim, size_t count) {
+  const uint32_t col = blockIdx.x * 256 + threadIdx.x;
+  const size_t c = blockIdx.y;
+  if (col > out_dim || c >= count) return;
+  ct_out[c * out_stride + col] = (col == out_dim) ? ct_in[c * in_stride + in_dim] : T(0);
 }
 
 }  // namespace
@@ -204,9 +230,25 @@ int launch_keyswitch(const T* ct_in, size_t in_stride, T* ct_out, size_t out_str
   const uint32_t ncols = out_dim + 1;
   const uint32_t per_block = KS_THREADS * KS_COLS;
   dim3 grid((unsigned)((count + KS_CT_TILE - 1) / KS_CT_TILE), (ncols + per_block - 1) / per_block);
+  // A CU holds four of these workgroups. Below KS_FILL workgroups the key rows are split as
+  // well, in ranges of at least KS_MIN_SPLIT chunks.
+  constexpr uint32_t KS_FILL = 1024, KS_MIN_SPLIT = 4;
+  const uint32_t chunks = in_dim / KS_CHUNK;
+  const uint64_t blocks = (uint64_t)grid.x * grid.y;
+  uint32_t splits = 1;
+  if (blocks < KS_FILL) splits = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)(KS_FILL / blocks), chunks / KS_MIN_SPLIT));
+  const uint32_t chunks_per_split = (chunks + splits - 1) / splits;
+  splits = (chunks + chunks_per_split - 1) / chunks_per_split;
+  if (splits > 1) {
+    if (count > 65535) return fail(CAMD_EINVAL, "keyswitch: internal split of a large batch");  // cannot happen: blocks < KS_FILL
+    hipLaunchKernelGGL(keyswitch_preset_kernel<T>, dim3((ncols + 255) / 256, (unsigned)count), dim3(256), 0, stream,
+                       ct_in, in_stride, ct_out, out_stride, in_dim, out_dim, count);
+    CAMD_HIP(hipGetLastError());
+  }
+  grid.z = splits;
   const size_t lds = (size_t)KS_CHUNK * level * KS_CT_TILE * sizeof(double);
   hipLaunchKernelGGL(keyswitch_kernel<T>, grid, dim3(KS_THREADS), lds, stream, ct_in, in_stride, ct_out,
-                     out_stride, ksk, in_dim, out_dim, base_log, level, count, flush_chunks);
+                     out_stride, ksk, in_dim, out_dim, base_log, level, count, flush_chunks, chunks_per_split);
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;
 }

@@ -58,6 +58,22 @@ def test_keyswitch_bit_exact_2_2(gpu_ctx, keys_2_2, variant):
     assert got.dtype == np.uint64 and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("count", [1, 17, 300, 1100])
+def test_keyswitch_small_batches_split_over_key_rows(gpu_ctx, keys_2_2, count):
+    """Below about a thousand workgroups the keyswitch also splits the key rows over workgroups
+    (16, 16, 13 and 3 ranges for these counts, the last range shorter than the others) and sums
+    the ranges with atomic adds: wrapping integer sums, so still bit for bit the oracle's."""
+    ks = keys_2_2
+    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    rs = np.random.RandomState(100 + count)
+    cts = rs.randint(0, 2 ** 63, size=(count, ks.o.big + 1), dtype=np.uint64) * np.uint64(2) + rs.randint(0, 2, size=(count, ks.o.big + 1)).astype(np.uint64)
+    got = dk.ks(cts)
+    pick = np.unique(np.concatenate([np.arange(min(count, 3)), np.arange(max(count - 3, 0), count), rs.randint(0, count, size=24)]))
+    want = np.stack([ks.o.keyswitch(ks.ksk, cts[i]) for i in pick])
+    assert np.array_equal(got[pick], want)
+    assert np.array_equal(dk.ks(cts), got)      # and the same on a second call, whatever the arrival order
+
+
 @pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC, CAMD_PBS_WAVE])
 def test_trivial_bootstrap_bit_exact_2_2(gpu_ctx, keys_2_2, variant):
     """Mask = 0 skips every CMUX: the output is the rotated look-up table, sample-extracted."""
