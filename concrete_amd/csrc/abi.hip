@@ -2,7 +2,9 @@
 // The header (include/concrete_amd.h) documents which reference interface each entry replaces.
 #include <cstdint>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <initializer_list>
 #include <mutex>
 #include <new>
@@ -65,6 +67,20 @@ struct Timing {
   }
 };
 
+enum class Op { KsPbs, PbsKs, Pbs, Ks };
+
+// One blocked caller of a host-pointer entry point.
+struct HostRequest {
+  Op op;
+  const void* in;
+  const uint32_t* ids;
+  void* out;
+  size_t count;
+  int rc = CAMD_OK;
+  std::string err;
+  bool done = false;
+};
+
 }  // namespace
 
 struct camd_server_key {
@@ -85,6 +101,11 @@ struct camd_server_key {
   DeviceBuffer stage_in, stage_out, stage_ids;
   std::mutex mu;
   Timing timing;
+  // host callers that arrive while a batch is on the GPU wait here and leave together, as one batch
+  std::mutex queue_mu;
+  std::condition_variable queue_cv;
+  std::deque<HostRequest*> queue;
+  bool serving = false;
 
   const double2* fbsk() const { return (const double2*)blob; }
   const void* ksk() const { return (const char*)blob + fbsk_bytes; }
@@ -282,8 +303,6 @@ int run_ks(camd_server_key* key, const T* in, size_t in_stride, T* out, size_t o
                              p.ks_base_log, p.ks_level, count, s);
 }
 
-enum class Op { KsPbs, PbsKs, Pbs, Ks };
-
 size_t in_words(const camd_server_key* k, Op op) {
   return (op == Op::KsPbs || op == Op::Ks) ? k->big() + 1 : (size_t)k->p.lwe_dimension + 1;
 }
@@ -398,27 +417,134 @@ int run_op_host(camd_server_key* key, Op op, const void* in, const uint32_t* d_i
   return CAMD_OK;
 }
 
+// One caller's batch, alone on the GPU.
+int serve_one(camd_server_key* key, const HostRequest& r) {
+  const size_t ib = r.count * in_words(key, r.op) * key->word, ob = r.count * out_words(key, r.op) * key->word;
+  int rc = key->stage_in.ensure(ib);
+  if (rc == CAMD_OK) rc = key->stage_out.ensure(ob);
+  if (rc == CAMD_OK && r.ids) rc = key->stage_ids.ensure(r.count * sizeof(uint32_t));
+  // scratch is sized once, for the whole batch, before any slice is in flight
+  if (rc == CAMD_OK) rc = reserve_locked(key, r.count);
+  if (rc != CAMD_OK) return rc;
+  if (r.ids) CAMD_HIP(hipMemcpyAsync(key->stage_ids.ptr, r.ids, r.count * sizeof(uint32_t), hipMemcpyHostToDevice, key->ctx->stream));
+  const uint32_t* d_ids = r.ids ? (const uint32_t*)key->stage_ids.ptr : nullptr;
+  return key->p.torus_bits == 64 ? run_op_host<uint64_t>(key, r.op, r.in, d_ids, r.out, r.count)
+                                 : run_op_host<uint32_t>(key, r.op, r.in, d_ids, r.out, r.count);
+}
+
+// Several callers' batches of one operation as one launch: inputs side by side in the staging
+// buffer, outputs copied back to each caller's buffer.
+int serve_many(camd_server_key* key, Op op, const std::vector<HostRequest*>& group) {
+  const size_t iw = in_words(key, op) * key->word, ow = out_words(key, op) * key->word;
+  size_t total = 0;
+  bool any_ids = false;
+  for (const HostRequest* r : group) {
+    total += r->count;
+    any_ids = any_ids || r->ids;
+  }
+  int rc = key->stage_in.ensure(total * iw);
+  if (rc == CAMD_OK) rc = key->stage_out.ensure(total * ow);
+  if (rc == CAMD_OK && any_ids) rc = key->stage_ids.ensure(total * sizeof(uint32_t));
+  if (rc == CAMD_OK) rc = reserve_locked(key, total);
+  if (rc != CAMD_OK) return rc;
+  hipStream_t s = key->ctx->stream;
+  hipError_t e = hipSuccess;
+  size_t first = 0;
+  for (const HostRequest* r : group) {
+    if (e == hipSuccess) e = hipMemcpyAsync((char*)key->stage_in.ptr + first * iw, r->in, r->count * iw, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && any_ids) {
+      uint32_t* d = (uint32_t*)key->stage_ids.ptr + first;   // no ids = table 0 for every ciphertext
+      e = r->ids ? hipMemcpyAsync(d, r->ids, r->count * sizeof(uint32_t), hipMemcpyHostToDevice, s)
+                 : hipMemsetAsync(d, 0, r->count * sizeof(uint32_t), s);
+    }
+    first += r->count;
+  }
+  if (e == hipSuccess) {
+    const uint32_t* d_ids = any_ids ? (const uint32_t*)key->stage_ids.ptr : nullptr;
+    rc = key->p.torus_bits == 64 ? run_op_device<uint64_t>(key, op, key->stage_in.ptr, d_ids, key->stage_out.ptr, total, s)
+                                 : run_op_device<uint32_t>(key, op, key->stage_in.ptr, d_ids, key->stage_out.ptr, total, s);
+  }
+  first = 0;
+  for (const HostRequest* r : group) {
+    if (e == hipSuccess && rc == CAMD_OK)
+      e = hipMemcpyAsync(r->out, (char*)key->stage_out.ptr + first * ow, r->count * ow, hipMemcpyDeviceToHost, s);
+    first += r->count;
+  }
+  const hipError_t e1 = hipStreamSynchronize(s);
+  if (rc != CAMD_OK) return rc;
+  for (hipError_t x : {e, e1})
+    if (x != hipSuccess) return fail(CAMD_EHIP, std::string("host-buffer batch: ") + hipGetErrorString(x));
+  return CAMD_OK;
+}
+
+// Runs the requests of one operation that were waiting; fills in rc / err of each.
+void serve(camd_server_key* key, Op op, std::vector<HostRequest*>& group) {
+  std::lock_guard<std::mutex> lock(key->mu);
+  DeviceGuard g(key->ctx->device);
+  std::vector<HostRequest*> good;
+  for (HostRequest* r : group) {
+    if (!g.ok) {
+      r->rc = CAMD_EHIP;
+      r->err = "hipSetDevice failed";
+      continue;
+    }
+    bool ids_ok = true;
+    if (r->ids)
+      for (size_t i = 0; i < r->count && ids_ok; i++) ids_ok = r->ids[i] < key->lut_count;
+    if (!ids_ok) {
+      r->rc = CAMD_EINVAL;
+      r->err = "lut id out of range";
+      continue;
+    }
+    good.push_back(r);
+  }
+  if (good.empty()) return;
+  const int rc = good.size() == 1 ? serve_one(key, *good[0]) : serve_many(key, op, good);
+  for (HostRequest* r : good) {
+    r->rc = rc;
+    if (rc != CAMD_OK) r->err = g_last_error;
+  }
+}
+
+// The reference calls this path one ciphertext at a time, from many threads (rayon in
+// concrete-integer's *_parallelized operations). A call that finds the key busy queues its
+// request; whoever is serving takes everything queued for one operation as ONE batch when the
+// GPU comes free, so concurrent single-ciphertext calls cost one launch, not one launch each.
+// A lone caller is served at once and alone, as before.
 int dispatch_host(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count) {
   if (!key || (!in && count) || (!out && count)) return fail(CAMD_EINVAL, "null argument");
   if (count == 0) return CAMD_OK;
-  std::lock_guard<std::mutex> lock(key->mu);
-  DeviceGuard g(key->ctx->device);
-  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
-  const size_t ib = count * in_words(key, op) * key->word, ob = count * out_words(key, op) * key->word;
-  int rc = key->stage_in.ensure(ib);
-  if (rc == CAMD_OK) rc = key->stage_out.ensure(ob);
-  if (rc == CAMD_OK && ids) rc = key->stage_ids.ensure(count * sizeof(uint32_t));
-  // scratch is sized once, for the whole batch, before any slice is in flight
-  if (rc == CAMD_OK) rc = reserve_locked(key, count);
-  if (rc != CAMD_OK) return rc;
-  if (ids) {
-    for (size_t i = 0; i < count; i++)
-      if (ids[i] >= key->lut_count) return fail(CAMD_EINVAL, "lut id out of range");
-    CAMD_HIP(hipMemcpyAsync(key->stage_ids.ptr, ids, count * sizeof(uint32_t), hipMemcpyHostToDevice, key->ctx->stream));
+  HostRequest req{op, in, ids, out, count};
+  std::unique_lock<std::mutex> q(key->queue_mu);
+  key->queue.push_back(&req);
+  while (!req.done && key->serving) key->queue_cv.wait(q);
+  if (!req.done) {
+    // nobody is serving: this caller does, until its own request is done
+    key->serving = true;
+    while (!req.done) {
+      std::vector<HostRequest*> group;
+      const Op group_op = key->queue.front()->op;
+      for (auto it = key->queue.begin(); it != key->queue.end();) {
+        if ((*it)->op == group_op) {
+          group.push_back(*it);
+          it = key->queue.erase(it);
+        } else {
+          ++it;
+        }
+      }
+      q.unlock();
+      serve(key, group_op, group);
+      q.lock();
+      for (HostRequest* r : group) r->done = true;
+      key->queue_cv.notify_all();
+    }
+    // whoever still waits (their requests are in the queue) elects the next server
+    key->serving = false;
+    key->queue_cv.notify_all();
   }
-  const uint32_t* d_ids = ids ? (const uint32_t*)key->stage_ids.ptr : nullptr;
-  return key->p.torus_bits == 64 ? run_op_host<uint64_t>(key, op, in, d_ids, out, count)
-                                 : run_op_host<uint32_t>(key, op, in, d_ids, out, count);
+  q.unlock();
+  if (req.rc != CAMD_OK) set_error(req.err);
+  return req.rc;
 }
 
 }  // namespace

@@ -9,8 +9,10 @@
  *   - every function returns 0 on success and a negative CAMD_E* code on failure; it never
  *     throws, aborts or prints. camd_last_error() returns the calling thread's last message.
  *   - "host" entry points take host pointers (pageable or pinned), block until the result is
- *     in the output buffer, and may be called concurrently on one key (calls are serialised
- *     per key). A large host batch is cut into slices of 2048 ciphertexts (environment
+ *     in the output buffer, and may be called concurrently on one key: calls that arrive
+ *     while the key is busy wait and are then run together, as one batch per operation (the
+ *     reference calls this path one ciphertext at a time from many threads; here such calls
+ *     share a launch). Each caller gets its own status and error message. A large host batch is cut into slices of 2048 ciphertexts (environment
  *     variable CAMD_HOST_CHUNK, 0 = one slice) so that the PCIe copies of one slice run
  *     beside the kernels of its neighbours; results do not depend on the slicing.
  *     "device" entry points take device pointers on the key's GPU plus a

@@ -255,6 +255,70 @@ def test_host_buffer_batch_is_sliced_without_changing_results(gpu_ctx, keys_2_2,
     assert np.array_equal(dk.ks(cts), np.stack([ks.o.keyswitch(ks.ksk, c) for c in cts]))
 
 
+def test_concurrent_single_ciphertext_callers_share_launches(gpu_ctx, keys_2_2):
+    """The reference bootstraps one ciphertext per call, from many threads. Callers that find the
+    key busy are served together, as one batch: every caller gets word for word what a lone call
+    gives (a lone call and a batch run the same per-ciphertext instruction sequence), a bad
+    argument of one caller fails that caller only, and 48 concurrent calls take far less than 48
+    calls one after the other."""
+    import threading
+    import time
+    from concrete_amd._ffi import CamdError
+
+    ks = keys_2_2
+    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    luts = [ks.o.generate_accumulator(f) for f in (lambda x: x % 4, lambda x: x // 4)]
+    for l in luts:
+        dk.upload_lut(l)
+    callers = 48
+    cts = encrypt_batch(ks, np.arange(callers) % 16)
+    lut_ids = (np.arange(callers) % 2).astype(np.uint32)
+    t0 = time.time()
+    alone = [dk.ks_pbs(cts[i], lut_ids[i:i + 1])[0] for i in range(8)]
+    one_call = (time.time() - t0) / 8
+
+    got, errors = [None] * callers, [None] * callers
+    gate = threading.Barrier(callers + 1)
+
+    def caller(i):
+        gate.wait()
+        try:
+            if i == 5:
+                dk.ks_pbs(cts[i], np.array([7], dtype=np.uint32))       # no such table
+            elif i % 3 == 0:
+                got[i] = dk.ks(cts[i])[0]                                 # another operation in between
+            elif i % 3 == 1:
+                got[i] = dk.ks_pbs(cts[i])[0]                             # no ids = table 0
+            else:
+                got[i] = dk.ks_pbs(cts[i], lut_ids[i:i + 1])[0]
+        except CamdError as e:
+            errors[i] = str(e)
+
+    threads = [threading.Thread(target=caller, args=(i,)) for i in range(callers)]
+    for t in threads:
+        t.start()
+    gate.wait()
+    t0 = time.time()
+    for t in threads:
+        t.join()
+    together = time.time() - t0
+
+    assert errors[5] is not None and "lut id out of range" in errors[5]
+    assert all(e is None for i, e in enumerate(errors) if i != 5)
+    whole0 = dk.ks_pbs(cts)                    # one batch, table 0
+    whole = dk.ks_pbs(cts, lut_ids)
+    small = dk.ks(cts)
+    for i in range(callers):
+        if i == 5:
+            continue
+        want = small[i] if i % 3 == 0 else whole0[i] if i % 3 == 1 else whole[i]
+        assert np.array_equal(got[i], want), i
+    for i in range(8):
+        assert np.array_equal(alone[i], whole[i])
+    print(f"one call {one_call * 1e3:.1f} ms; {callers} concurrent calls {together * 1e3:.1f} ms")
+    assert together < 0.5 * callers * one_call
+
+
 def test_other_wave_schedules_in_their_own_process():
     """The schedule of the wave family is chosen once per process (CAMD_WAVE_SCHEDULE); the first
     (one row at a time) and third (two waves per SIMD) schedules are kept as selectable variants and
