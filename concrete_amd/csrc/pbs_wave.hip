@@ -1171,6 +1171,129 @@ void wave_pbs_kernel_v3(PbsLaunch<T> a) {
   }
 }
 
+// ---- the bootstrap, latency schedule: k+1 waves per ciphertext ----
+// A batch smaller than the chip leaves most SIMDs idle while each lone wave walks its n CMUXes
+// at one instruction per four cycles. Here the k+1 waves of a workgroup share one ciphertext:
+// wave c owns polynomial c of the accumulator (in registers, as in the third schedule), rotates,
+// decomposes and forward-transforms it, and publishes the spectrum in LDS; after one barrier it
+// multiplies all k+1 spectra with column c of the key row (requested at the top of the
+// iteration, so the loads fly behind the forward transform), transforms back and adds into its
+// polynomial. One transform each way per wave and CMUX instead of k+1. The spectra alternate
+// between two images, so one barrier per CMUX is enough: a wave can only overwrite an image after
+// the barrier of the following CMUX, which every reader of that image has reached by then.
+// Same products in the same order as the third schedule, hence the same ciphertext words.
+template <typename T, int K>
+constexpr size_t wavelat_lds_bytes() {
+  return TAB_COUNT * sizeof(double2) + (K + 1) * wave3_slab_bytes<T, K>() + 2 * (K + 1) * 512 * sizeof(double2);
+}
+
+template <typename T, int K, int BL>
+__global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T> a) {
+  constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1, NS = R * R;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * R) tab[t] = a.tables[t];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = the polynomial this wave owns
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * wave3_slab_bytes<T, K>();
+  double* sre = (double*)slab;
+  double* sim = sre + PLANE;
+  T* stage = (T*)(slab + 2 * PLANE * sizeof(double));
+  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * wave3_slab_bytes<T, K>());  // [2][R][8][64]
+  const uint32_t n = a.n;
+  uint32_t image = 0;
+
+  for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
+    const T* in = a.ct_in + ct * a.in_stride;
+    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
+    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N) + (size_t)wave * N;
+
+    // acc[2q] = coefficient 64q + lane, acc[2q+1] = coefficient 64q + lane + N/2 of the own polynomial
+    T acc[16];
+    {
+      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        acc[2 * q] = rotated_coeff<T>(lut, 64 * q + lane, d0, N);
+        acc[2 * q + 1] = rotated_coeff<T>(lut, 64 * q + lane + M, d0, N);
+      }
+    }
+
+    T a_next = wave_uniform(in[0]);
+    for (uint32_t i = 0; i < n; i++) {
+      const T a_cur = a_next;
+      a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
+      if (a_cur == 0) continue;           // the reference skips these too; every wave of the group sees the same value
+      const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
+
+      // column `wave` of key row i
+      const double2* key = a.fbsk + (size_t)i * NS * M + (size_t)wave * M + lane;
+      double2 kk[R][8];
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int g = 0; g < 8; g++) kk[r][g] = key[(size_t)(r * R) * M + g * 64];
+
+      // rotation by X^a_hat through the staging row, then the digits of (rotated - own)
+      double2 x[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        stage[64 * q + lane] = acc[2 * q];
+        stage[64 * q + lane + M] = acc[2 * q + 1];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+        const T v0 = stage[(j0 - a_hat) & (N - 1)], v1 = stage[(j1 - a_hat) & (N - 1)];
+        const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - v0) : v0;
+        const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - v1) : v1;
+        uint32_t s0 = digit_state32<T, BL, L>((T)(r0 - acc[2 * q]));
+        uint32_t s1 = digit_state32<T, BL, L>((T)(r1 - acc[2 * q + 1]));
+        const int32_t d0 = digit_next32<BL, L>(s0), d1 = digit_next32<BL, L>(s1);
+        x[q] = cmul(make_double2((double)d0, (double)d1), tab[TAB_TWIST + 64 * q + lane]);
+      }
+      fft512_forward(x, lane, tab, sre, sim);
+
+      double2* img = spectra + (size_t)image * (R * M);
+#pragma unroll
+      for (int g = 0; g < 8; g++) img[(wave * 8 + g) * 64 + lane] = x[g];
+      __syncthreads();
+      image ^= 1u;
+
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        double2 v = cmul(kk[0][g], img[(0 * 8 + g) * 64 + lane]);
+#pragma unroll
+        for (int r = 1; r < R; r++) v = cfma(kk[r][g], img[(r * 8 + g) * 64 + lane], v);
+        x[g] = v;
+      }
+      fft512_inverse(x, lane, tab, sre, sim);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const double2 v = cmul_conj(x[q], tab[TAB_TWIST + 64 * q + lane]);
+        acc[2 * q] = torus_accumulate(acc[2 * q], v.x);
+        acc[2 * q + 1] = torus_accumulate(acc[2 * q + 1], v.y);
+      }
+    }
+
+    // sample extraction of coefficient 0: out[c N + (N - j) mod N] = (j == 0) ? p[j] : -p[j]
+    T* out = a.ct_out + ct * a.out_stride;
+    if (wave < K) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+        out[(size_t)wave * N + ((N - j0) & (N - 1))] = (j0 == 0) ? acc[2 * q] : (T)(T(0) - acc[2 * q]);
+        out[(size_t)wave * N + (N - j1)] = (T)(T(0) - acc[2 * q + 1]);
+      }
+    } else if (lane == 0) {
+      out[K * N] = acc[0];
+    }
+  }
+}
+
 // ================================================================================================
 // N = 512 instance (the boolean default parameters: 32-bit torus, k = 2, two levels, base 2^8).
 // Same schedule as wave_pbs_kernel_v2 — one wave per ciphertext, the transforms of a CMUX
@@ -1583,6 +1706,26 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     return e ? atoi(e) : 2;
   }();
   if constexpr (L == 1) {
+    // fewer ciphertexts than CUs: k+1 waves share each one (CAMD_WAVE_LATENCY=0 keeps the
+    // one-wave-per-ciphertext schedules for every batch size)
+    static const bool latency = []() {
+      const char* e = getenv("CAMD_WAVE_LATENCY");
+      return !e || atoi(e) != 0;
+    }();
+    if (latency) {
+      int dev = 0, cus = 0;
+      CAMD_HIP(hipGetDevice(&dev));
+      CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      if (a.count <= (size_t)cus) {
+        constexpr size_t ldsl = wavelat_lds_bytes<T, K>();
+        static_assert(ldsl <= 160 * 1024, "LDS budget exceeded");
+        auto kernl = wave_pbs_kernel_lat<T, K, BL>;
+        CAMD_HIP(hipFuncSetAttribute((const void*)kernl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl));
+        hipLaunchKernelGGL(kernl, dim3((unsigned)a.count), dim3(64 * (K + 1)), ldsl, stream, a);
+        CAMD_HIP(hipGetLastError());
+        return CAMD_OK;
+      }
+    }
     if (schedule == 3) {
       constexpr size_t lds3 = wave3_lds_bytes<T, K>();
       static_assert(lds3 <= 160 * 1024, "LDS budget exceeded");

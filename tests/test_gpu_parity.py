@@ -322,17 +322,59 @@ def test_concurrent_single_ciphertext_callers_share_launches(gpu_ctx, keys_2_2):
 def test_other_wave_schedules_in_their_own_process():
     """The schedule of the wave family is chosen once per process (CAMD_WAVE_SCHEDULE); the first
     (one row at a time) and third (two waves per SIMD) schedules are kept as selectable variants and
-    must meet the same parity bar as the default."""
+    must meet the same parity bar as the default. Batches smaller than the chip normally go to the
+    latency schedule (k+1 waves per ciphertext); CAMD_WAVE_LATENCY=0 sends them to the selected
+    schedule, so the small cases are run that way for all three."""
     import os
     import subprocess
     import sys
 
-    if os.environ.get("CAMD_WAVE_SCHEDULE"):
+    if os.environ.get("CAMD_WAVE_SCHEDULE") or os.environ.get("CAMD_WAVE_LATENCY"):
         pytest.skip("already running under a non-default schedule")
     here = os.path.abspath(__file__)
-    for schedule in ("1", "3"):
-        env = dict(os.environ, CAMD_WAVE_SCHEDULE=schedule)
+    for schedule in ("1", "2", "3"):
+        env = dict(os.environ, CAMD_WAVE_SCHEDULE=schedule, CAMD_WAVE_LATENCY="0")
         res = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
                               "ks_pbs_parity_2_2 or trivial_bootstrap or persistent_rounds", "-p", "no:cacheprovider"],
                              env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, f"schedule {schedule}:\n" + res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def _schedule_probe(gpu_ctx, ks):
+    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    for f in (lambda x: x % 4, lambda x: x // 4):
+        dk.upload_lut(ks.o.generate_accumulator(f))
+    rs = np.random.RandomState(77)
+    count = 40
+    cts = rs.randint(0, 2 ** 63, size=(count, ks.o.big + 1), dtype=np.uint64) * np.uint64(2) + rs.randint(0, 2, size=(count, ks.o.big + 1)).astype(np.uint64)
+    return dk.ks_pbs(cts, (np.arange(count) % 2).astype(np.uint32))
+
+
+def test_dump_for_schedule_comparison(gpu_ctx, keys_2_2):
+    """Helper of the next test: writes this process's outputs where CAMD_DUMP says."""
+    import os
+
+    path = os.environ.get("CAMD_DUMP")
+    if not path:
+        pytest.skip("only run as a child of the schedule comparison")
+    np.save(path, _schedule_probe(gpu_ctx, keys_2_2))
+
+
+def test_latency_schedule_gives_the_words_of_the_third_schedule(gpu_ctx, keys_2_2, tmp_path):
+    """k+1 waves per ciphertext perform the products and transforms of the third schedule in the
+    same order, so a small batch (latency schedule) and the same batch under CAMD_WAVE_SCHEDULE=3
+    agree word for word."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("CAMD_WAVE_SCHEDULE") or os.environ.get("CAMD_WAVE_LATENCY"):
+        pytest.skip("already running under a non-default schedule")
+    here = os.path.abspath(__file__)
+    got = _schedule_probe(gpu_ctx, keys_2_2)
+    path = str(tmp_path / "third.npy")
+    env = dict(os.environ, CAMD_WAVE_SCHEDULE="3", CAMD_WAVE_LATENCY="0", CAMD_DUMP=path)
+    res = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "dump_for_schedule_comparison",
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert np.array_equal(got, np.load(path))
