@@ -53,6 +53,16 @@ constexpr int TAB_COUNT = TAB_TW1 + 7 * 8;
 
 constexpr double HALF_SQRT2 = 0.70710678118654752440;
 
+// Batches of at most one ciphertext per CU go to the kernels that give a ciphertext k+1 waves;
+// CAMD_WAVE_LATENCY=0 keeps the one-wave-per-ciphertext schedules for every batch size.
+inline bool wave_latency_enabled() {
+  static const bool on = []() {
+    const char* e = getenv("CAMD_WAVE_LATENCY");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+
 __device__ __forceinline__ double2 mul_neg_i(double2 v) { return make_double2(v.y, -v.x); }
 __device__ __forceinline__ double2 mul_pos_i(double2 v) { return make_double2(-v.y, v.x); }
 
@@ -1648,6 +1658,134 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
   }
 }
 
+// Latency variant (see wave_pbs_kernel_lat): k+1 waves per ciphertext, wave c owning polynomial
+// c. It transforms the L digit polynomials of its own polynomial, publishes them, and after the
+// barrier accumulates column c over all (k+1) L spectra in the order of pbs_kernel, so both give
+// the same ciphertext words.
+template <typename T>
+constexpr size_t lat_slab_bytes() { return (size_t)N * sizeof(T) + 2 * PLANE * sizeof(double); }
+template <typename T, int K, int L>
+constexpr size_t lat_lds_bytes() {
+  return TAB_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T>() + 2 * (size_t)(K + 1) * L * M * sizeof(double2);
+}
+
+template <typename T, int K, int L, int BL>
+__global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
+  constexpr int R = K + 1, S = R * L, NS = S * R;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * R) tab[t] = a.tables[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = the polynomial this wave owns
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T>();
+  T* stage = (T*)slab;
+  double* sre = (double*)(slab + (size_t)N * sizeof(T));
+  double* sim = sre + PLANE;
+  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T>());  // [2][S][4][64]
+  const uint32_t n = a.n;
+  uint32_t image = 0;
+
+  for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
+    const T* in = a.ct_in + ct * a.in_stride;
+    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
+    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N) + (size_t)wave * N;
+    // acc[2q] = coefficient 64q + lane, acc[2q+1] = coefficient 64q + lane + N/2 of the own polynomial
+    T acc[8];
+    {
+      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        acc[2 * q] = rotated_coeff<T>(lut, 64 * q + lane, d0, N);
+        acc[2 * q + 1] = rotated_coeff<T>(lut, 64 * q + lane + M, d0, N);
+      }
+    }
+    T a_next = wave_uniform(in[0]);
+    for (uint32_t i = 0; i < n; i++) {
+      const T a_cur = a_next;
+      a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
+      if (a_cur == 0) continue;           // skipped by every wave of the group alike
+      const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
+
+      // column `wave` of key row i, every stream
+      const double2* key = a.fbsk + (size_t)i * NS * M + (size_t)wave * M + lane;
+      double2 kk[S][4];
+#pragma unroll
+      for (int st = 0; st < S; st++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) kk[st][g] = key[(size_t)(st * R) * M + g * 64];
+
+      double2 x[L][4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        stage[64 * q + lane] = acc[2 * q];
+        stage[64 * q + lane + M] = acc[2 * q + 1];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+        const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
+        const T rot0 = stage[s0 & (N - 1)], rot1 = stage[s1 & (N - 1)];
+        const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
+        const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
+        const double2 tw = tab[TAB_TWIST + j0];
+        if constexpr (L == 1) {
+          const int32_t g0 = digit_single32<T, BL>((T)(r0 - acc[2 * q]));
+          const int32_t g1 = digit_single32<T, BL>((T)(r1 - acc[2 * q + 1]));
+          x[0][q] = cmul(make_double2((double)g0, (double)g1), tw);
+        } else {
+          uint32_t st0 = digit_state32<T, BL, L>((T)(r0 - acc[2 * q]));
+          uint32_t st1 = digit_state32<T, BL, L>((T)(r1 - acc[2 * q + 1]));
+#pragma unroll
+          for (int l = L; l >= 1; l--) {
+            const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
+            x[l - 1][q] = cmul(make_double2((double)g0, (double)g1), tw);
+          }
+        }
+      }
+      fft256_forward_multi<L>(x, lane, tab, sre, sim);
+
+      double2* img = spectra + (size_t)image * (S * M);
+#pragma unroll
+      for (int l = 0; l < L; l++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) img[((l * R + wave) * 4 + g) * 64 + lane] = x[l][g];
+      __syncthreads();
+      image ^= 1u;
+
+      double2 y[1][4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        double2 v = cmul(kk[0][g], img[(0 * 4 + g) * 64 + lane]);
+#pragma unroll
+        for (int st = 1; st < S; st++) v = cfma(kk[st][g], img[(st * 4 + g) * 64 + lane], v);
+        y[0][g] = v;
+      }
+      fft256_inverse_multi<1>(y, lane, tab, sre, sim);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double2 v = cmul_conj(y[0][q], tab[TAB_TWIST + 64 * q + lane]);
+        acc[2 * q] = torus_accumulate(acc[2 * q], v.x);
+        acc[2 * q + 1] = torus_accumulate(acc[2 * q + 1], v.y);
+      }
+    }
+
+    // sample extraction of coefficient 0: out[c N + (N - j) mod N] = (j == 0) ? p[j] : -p[j]
+    T* out = a.ct_out + ct * a.out_stride;
+    if (wave < K) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+        out[(size_t)wave * N + ((N - j0) & (N - 1))] = (j0 == 0) ? acc[2 * q] : (T)(T(0) - acc[2 * q]);
+        out[(size_t)wave * N + (N - j1)] = (T)(T(0) - acc[2 * q + 1]);
+      }
+    } else if (lane == 0) {
+      out[K * N] = acc[0];
+    }
+  }
+}
+
 inline bool supported(const camd_params& p) {
   if (p.polynomial_size != 512) return false;
   if (p.torus_bits == 32) return p.glwe_dimension == 2 && p.pbs_level == 2 && p.pbs_base_log == 8;
@@ -1684,6 +1822,15 @@ int launch(const PbsLaunch<T>& a, hipStream_t stream) {
   int dev = 0, cus = 0;
   CAMD_HIP(hipGetDevice(&dev));
   CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (wave_latency_enabled() && a.count <= (size_t)cus) {
+    constexpr size_t ldsl = lat_lds_bytes<T, K, L>();
+    static_assert(ldsl <= 160 * 1024, "LDS budget exceeded");
+    auto kernl = pbs_kernel_lat<T, K, L, BL>;
+    if (ldsl > 64 * 1024) CAMD_HIP(hipFuncSetAttribute((const void*)kernl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl));
+    hipLaunchKernelGGL(kernl, dim3((unsigned)a.count), dim3(64 * (K + 1)), ldsl, stream, a);
+    CAMD_HIP(hipGetLastError());
+    return CAMD_OK;
+  }
   const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
   const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // one wave per SIMD (512 registers)
   if (persistent < grid) {
@@ -1706,13 +1853,8 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     return e ? atoi(e) : 2;
   }();
   if constexpr (L == 1) {
-    // fewer ciphertexts than CUs: k+1 waves share each one (CAMD_WAVE_LATENCY=0 keeps the
-    // one-wave-per-ciphertext schedules for every batch size)
-    static const bool latency = []() {
-      const char* e = getenv("CAMD_WAVE_LATENCY");
-      return !e || atoi(e) != 0;
-    }();
-    if (latency) {
+    // fewer ciphertexts than CUs: k+1 waves share each one
+    if (wave_latency_enabled()) {
       int dev = 0, cus = 0;
       CAMD_HIP(hipGetDevice(&dev));
       CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));

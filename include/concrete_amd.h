@@ -63,9 +63,9 @@ typedef struct camd_params {
  * decryptions and the noise bound are the same, the last bits of a ciphertext may differ. AUTO
  * picks WAVE for the shortint sets that have an instance (N = 1024 with k = 2, N = 512 with k = 3)
  * and BLOCK otherwise; the WAVE instance for the boolean default parameters (N = 512, 32-bit
- * torus) is selected by asking for it. A WAVE batch of at most one ciphertext per CU runs (for
- * N = 1024) on a variant that gives each ciphertext k+1 wavefronts: half the latency, same
- * decryptions, words may differ from those the same ciphertext gets inside a large batch; the
+ * torus) is selected by asking for it. A WAVE batch of at most one ciphertext per CU runs on a
+ * variant that gives each ciphertext k+1 wavefronts: half the latency, same
+ * decryptions, for N = 1024 words may differ from those the same ciphertext gets inside a large batch; the
  * environment variable CAMD_WAVE_LATENCY=0 disables it. */
 #define CAMD_PBS_AUTO 0
 #define CAMD_PBS_GENERIC 1
