@@ -12,12 +12,12 @@
  *     in the output buffer, and may be called concurrently on one key: calls that arrive
  *     while the key is busy wait and are then run together, as one batch per operation (the
  *     reference calls this path one ciphertext at a time from many threads; here such calls
- *     share a launch). Each caller gets its own status and error message. A large host batch is cut into slices of 2048 ciphertexts (environment
- *     variable CAMD_HOST_CHUNK, 0 = one slice) so that the PCIe copies of one slice run
- *     beside the kernels of its neighbours; results do not depend on the slicing.
- *     "device" entry points take device pointers on the key's GPU plus a
- *     hipStream_t (as void*, NULL = the default stream), enqueue the kernels and return
- *     without synchronising.
+ *     share a launch). Each caller gets its own status and error message. A large host batch
+ *     is cut into slices of 2048 ciphertexts (environment variable CAMD_HOST_CHUNK, 0 = one
+ *     slice) so that the PCIe copies of one slice run beside the kernels of its neighbours;
+ *     results do not depend on the slicing.
+ *   - "device" entry points take device pointers on the key's GPU plus a hipStream_t (as
+ *     void*, NULL = the default stream), enqueue the kernels and return without synchronising.
  *   - LWE ciphertexts are dim+1 torus words, body last. GLWE ciphertexts (look-up tables) are
  *     (k+1)*N words, mask polynomials first, body polynomial last.
  *   - standard bootstrap key layout: [n][level][k+1 rows][k+1 cols][N] words, level 1
@@ -64,9 +64,9 @@ typedef struct camd_params {
  * picks WAVE for the shortint sets that have an instance (N = 1024 with k = 2, N = 512 with k = 3)
  * and BLOCK otherwise; the WAVE instance for the boolean default parameters (N = 512, 32-bit
  * torus) is selected by asking for it. A WAVE batch of at most one ciphertext per CU runs on a
- * variant that gives each ciphertext k+1 wavefronts: half the latency, same
- * decryptions, for N = 1024 words may differ from those the same ciphertext gets inside a large batch; the
- * environment variable CAMD_WAVE_LATENCY=0 disables it. */
+ * variant that gives each ciphertext k+1 wavefronts: less than half the latency, same
+ * decryptions; for N = 1024 the words may differ from those the same ciphertext gets inside a
+ * large batch. The environment variable CAMD_WAVE_LATENCY=0 disables it. */
 #define CAMD_PBS_AUTO 0
 #define CAMD_PBS_GENERIC 1
 #define CAMD_PBS_WAVE 2
