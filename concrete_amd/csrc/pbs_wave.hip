@@ -1192,14 +1192,14 @@ void wave_pbs_kernel_v3(PbsLaunch<T> a) {
 // between two images, so one barrier per CMUX is enough: a wave can only overwrite an image after
 // the barrier of the following CMUX, which every reader of that image has reached by then.
 // Same products in the same order as the third schedule, hence the same ciphertext words.
-template <typename T, int K>
+template <typename T, int K, int L>
 constexpr size_t wavelat_lds_bytes() {
-  return TAB_COUNT * sizeof(double2) + (K + 1) * wave3_slab_bytes<T, K>() + 2 * (K + 1) * 512 * sizeof(double2);
+  return TAB_COUNT * sizeof(double2) + (K + 1) * wave3_slab_bytes<T, K>() + 2 * (size_t)(K + 1) * L * 512 * sizeof(double2);
 }
 
-template <typename T, int K, int BL>
+template <typename T, int K, int L, int BL>
 __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T> a) {
-  constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1, NS = R * R;
+  constexpr int N = 1024, M = 512, LOGN = 10, R = K + 1, S = R * L, NS = S * R;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
   for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * R) tab[t] = a.tables[t];
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
   double* sre = (double*)slab;
   double* sim = sre + PLANE;
   T* stage = (T*)(slab + 2 * PLANE * sizeof(double));
-  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * wave3_slab_bytes<T, K>());  // [2][R][8][64]
+  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * wave3_slab_bytes<T, K>());  // [2][S][8][64]
   const uint32_t n = a.n;
   uint32_t image = 0;
 
@@ -1239,16 +1239,16 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
       if (a_cur == 0) continue;           // the reference skips these too; every wave of the group sees the same value
       const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
 
-      // column `wave` of key row i
+      // column `wave` of key row i: stream (level l, row r) at index (l - 1) R + r
       const double2* key = a.fbsk + (size_t)i * NS * M + (size_t)wave * M + lane;
-      double2 kk[R][8];
+      double2 kk[S][8];
 #pragma unroll
-      for (int r = 0; r < R; r++)
+      for (int st = 0; st < S; st++)
 #pragma unroll
-        for (int g = 0; g < 8; g++) kk[r][g] = key[(size_t)(r * R) * M + g * 64];
+        for (int g = 0; g < 8; g++) kk[st][g] = key[(size_t)(st * R) * M + g * 64];
 
       // rotation by X^a_hat through the staging row, then the digits of (rotated - own)
-      double2 x[8];
+      uint32_t st0[8], st1[8];
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         stage[64 * q + lane] = acc[2 * q];
@@ -1260,24 +1260,37 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
         const T v0 = stage[(j0 - a_hat) & (N - 1)], v1 = stage[(j1 - a_hat) & (N - 1)];
         const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - v0) : v0;
         const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - v1) : v1;
-        uint32_t s0 = digit_state32<T, BL, L>((T)(r0 - acc[2 * q]));
-        uint32_t s1 = digit_state32<T, BL, L>((T)(r1 - acc[2 * q + 1]));
-        const int32_t d0 = digit_next32<BL, L>(s0), d1 = digit_next32<BL, L>(s1);
-        x[q] = cmul(make_double2((double)d0, (double)d1), tab[TAB_TWIST + 64 * q + lane]);
+        st0[q] = digit_state32<T, BL, L>((T)(r0 - acc[2 * q]));
+        st1[q] = digit_state32<T, BL, L>((T)(r1 - acc[2 * q + 1]));
       }
-      fft512_forward(x, lane, tab, sre, sim);
-
-      double2* img = spectra + (size_t)image * (R * M);
+      double2* img = spectra + (size_t)image * (S * M);
+      double2 x[8];
 #pragma unroll
-      for (int g = 0; g < 8; g++) img[(wave * 8 + g) * 64 + lane] = x[g];
+      for (int l = L; l >= 1; l--) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int32_t d0 = digit_next32<BL, L>(st0[q]), d1 = digit_next32<BL, L>(st1[q]);
+          x[q] = cmul(make_double2((double)d0, (double)d1), tab[TAB_TWIST + 64 * q + lane]);
+        }
+        fft512_forward(x, lane, tab, sre, sim);
+#pragma unroll
+        for (int g = 0; g < 8; g++) img[(((l - 1) * R + wave) * 8 + g) * 64 + lane] = x[g];
+      }
       __syncthreads();
       image ^= 1u;
 
+      // rows outermost, levels from the finest up: the order of the one-wave schedules
 #pragma unroll
       for (int g = 0; g < 8; g++) {
-        double2 v = cmul(kk[0][g], img[(0 * 8 + g) * 64 + lane]);
+        double2 v = cmul(kk[(L - 1) * R][g], img[(((L - 1) * R) * 8 + g) * 64 + lane]);
 #pragma unroll
-        for (int r = 1; r < R; r++) v = cfma(kk[r][g], img[(r * 8 + g) * 64 + lane], v);
+        for (int r = 0; r < R; r++)
+#pragma unroll
+          for (int l = L; l >= 1; l--) {
+            if (r == 0 && l == L) continue;
+            const int st = (l - 1) * R + r;
+            v = cfma(kk[st][g], img[(st * 8 + g) * 64 + lane], v);
+          }
         x[g] = v;
       }
       fft512_inverse(x, lane, tab, sre, sim);
@@ -1852,22 +1865,22 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     const char* e = getenv("CAMD_WAVE_SCHEDULE");
     return e ? atoi(e) : 2;
   }();
-  if constexpr (L == 1) {
-    // fewer ciphertexts than CUs: k+1 waves share each one
-    if (wave_latency_enabled()) {
-      int dev = 0, cus = 0;
-      CAMD_HIP(hipGetDevice(&dev));
-      CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      if (a.count <= (size_t)cus) {
-        constexpr size_t ldsl = wavelat_lds_bytes<T, K>();
-        static_assert(ldsl <= 160 * 1024, "LDS budget exceeded");
-        auto kernl = wave_pbs_kernel_lat<T, K, BL>;
-        CAMD_HIP(hipFuncSetAttribute((const void*)kernl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl));
-        hipLaunchKernelGGL(kernl, dim3((unsigned)a.count), dim3(64 * (K + 1)), ldsl, stream, a);
-        CAMD_HIP(hipGetLastError());
-        return CAMD_OK;
-      }
+  // fewer ciphertexts than CUs: k+1 waves share each one
+  if (wave_latency_enabled()) {
+    int dev = 0, cus = 0;
+    CAMD_HIP(hipGetDevice(&dev));
+    CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (a.count <= (size_t)cus) {
+      constexpr size_t ldsl = wavelat_lds_bytes<T, K, L>();
+      static_assert(ldsl <= 160 * 1024, "LDS budget exceeded");
+      auto kernl = wave_pbs_kernel_lat<T, K, L, BL>;
+      CAMD_HIP(hipFuncSetAttribute((const void*)kernl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl));
+      hipLaunchKernelGGL(kernl, dim3((unsigned)a.count), dim3(64 * (K + 1)), ldsl, stream, a);
+      CAMD_HIP(hipGetLastError());
+      return CAMD_OK;
     }
+  }
+  if constexpr (L == 1) {
     if (schedule == 3) {
       constexpr size_t lds3 = wave3_lds_bytes<T, K>();
       static_assert(lds3 <= 160 * 1024, "LDS budget exceeded");
@@ -1920,7 +1933,14 @@ bool wave_default(const camd_params& p) {
   return w4::supported(p);
 }
 
-bool wave_supported(const camd_params& p) { return wave_default(p) || w4::supported(p); }
+// the boolean TFHE-lib parameters (32-bit torus, N = 1024, k = 1, three levels of base 2^7): first
+// schedule for large batches, the k+1-wave variant for small ones; on request, like the other
+// boolean instance
+static bool tfhe_lib_instance(const camd_params& p) {
+  return p.torus_bits == 32 && p.polynomial_size == 1024 && p.glwe_dimension == 1 && p.pbs_level == 3 && p.pbs_base_log == 7;
+}
+
+bool wave_supported(const camd_params& p) { return wave_default(p) || w4::supported(p) || tfhe_lib_instance(p); }
 
 size_t wave_tables_count(uint32_t N) { return N == 512 ? (size_t)w4::TAB_COUNT : (size_t)TAB_COUNT; }
 
@@ -1973,6 +1993,7 @@ int wave_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
     if (a.N == 512 && a.k == 3 && a.level == 1 && a.base_log == 18) return w4::launch<T, 3, 1, 18>(a, stream);
   } else {
     if (a.N == 512 && a.k == 2 && a.level == 2 && a.base_log == 8) return w4::launch<T, 2, 2, 8>(a, stream);
+    if (a.N == 1024 && a.k == 1 && a.level == 3 && a.base_log == 7) return launch_instance<T, 1, 3, 7>(a, stream);
   }
   return fail(CAMD_EINVAL, "wave kernel: no instance for this parameter set");
 }

@@ -257,6 +257,54 @@ def test_boolean_wave_kernel_full_size(gpu_ctx):
     dk.close()
 
 
+def test_tfhe_lib_wave_kernel_full_size(gpu_ctx):
+    """The wave instance for the boolean TFHE-lib parameters (N = 1024, k = 1, three levels; on
+    request), full n = 630, against the oracle: every decryption identical and every gate of the
+    truth table right. A small batch runs on the k+1-wave variant, a large one on the one-wave
+    schedule; both accumulate the products in the same order, so they give the same words. Against
+    the oracle (another order of f64 operations) words agree to the last units of the 32-bit torus
+    unless a last-unit difference tips the rounding of a decomposition (21 of 32 bits kept), after
+    which masks differ while decryptions do not: most ciphertexts must be within 2 units."""
+    p = P.TFHE_LIB_PARAMETERS
+    ks = get_keys(p, 32)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    assert dk.variant == CAMD_PBS_WAVE
+    acc = o.boolean_accumulator()
+    dk.upload_lut(acc)
+    T, F = 1 << 29, 7 << 29
+    rows, want_bits = [], []
+    for rep in range(8):
+        for a in (False, True):
+            for b in (False, True):
+                ca = o.lwe_encrypt(ks.rng, ks.small, T if a else F, p.lwe_modular_std_dev)
+                cb = o.lwe_encrypt(ks.rng, ks.small, T if b else F, p.lwe_modular_std_dev)
+                buf = (np.uint32(0) - (ca + cb)).astype(np.uint32)
+                buf[-1] = np.uint32((int(buf[-1]) + T) & 0xFFFFFFFF)
+                rows.append(buf)
+                want_bits.append(not (a and b))
+    cts = np.stack(rows)
+    want_big = np.stack([o.bootstrap(ks.fbsk, acc, c) for c in cts])
+    got_big = dk.pbs(cts)
+    diff = (got_big.astype(np.int64) - want_big.astype(np.int64) + (1 << 31)) % (1 << 32) - (1 << 31)
+    close = np.abs(diff).max(axis=1) <= 2
+    print(f"ciphertexts within 2 units of the oracle: {int(close.sum())} of {len(close)}")
+    assert close.sum() >= 0.75 * len(close)
+    for i, bit in enumerate(want_bits):
+        assert (o.lwe_phase(ks.glwe, got_big[i]) < (1 << 31)) == bit
+        assert (o.lwe_phase(ks.glwe, want_big[i]) < (1 << 31)) == bit
+    got = dk.pbs_ks(cts)
+    want = o.pbs_ks_batch(ks.ksk, ks.fbsk, acc, None, cts, threads=8)
+    for i, bit in enumerate(want_bits):
+        assert (o.lwe_phase(ks.small, got[i]) < (1 << 31)) == bit
+        assert (o.lwe_phase(ks.small, want[i]) < (1 << 31)) == bit
+    # more ciphertexts than CUs: the one-wave schedule, ragged last workgroup; same words
+    many = np.tile(cts, (40, 1))[:1027]
+    out = dk.pbs_ks(many)
+    assert np.array_equal(out[:32], got) and np.array_equal(out[992:1024], got) and np.array_equal(out[1024:], got[:3])
+    dk.close()
+
+
 @pytest.mark.parametrize("pname", ["PARAM_MESSAGE_1_CARRY_2", "PARAM_MESSAGE_2_CARRY_1", "PARAM_MESSAGE_3_CARRY_0"])
 def test_wave_kernel_small_shortint_sets(gpu_ctx, pname):
     """The N = 512 wave instance on the three small shortint sets (64-bit torus, k = 3, one level),
