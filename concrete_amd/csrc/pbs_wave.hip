@@ -53,14 +53,16 @@ constexpr int TAB_COUNT = TAB_TW1 + 7 * 8;
 
 constexpr double HALF_SQRT2 = 0.70710678118654752440;
 
-// Batches of at most one ciphertext per CU go to the kernels that give a ciphertext k+1 waves;
-// CAMD_WAVE_LATENCY=0 keeps the one-wave-per-ciphertext schedules for every batch size.
-inline bool wave_latency_enabled() {
-  static const bool on = []() {
+// Small batches go to the kernels that give a ciphertext k+1 waves: up to `fit` ciphertexts per
+// CU, where `fit` is the number of such workgroups a CU holds at once. CAMD_WAVE_LATENCY=0 keeps
+// the one-wave-per-ciphertext schedules for every batch size; a positive value replaces `fit`.
+inline size_t wave_latency_limit(int cus, int fit) {
+  static const int setting = []() {
     const char* e = getenv("CAMD_WAVE_LATENCY");
-    return !e || atoi(e) != 0;
+    return e ? atoi(e) : -1;
   }();
-  return on;
+  if (setting == 0 || cus <= 0) return 0;
+  return (size_t)cus * (size_t)(setting > 0 ? setting : fit);
 }
 
 __device__ __forceinline__ double2 mul_neg_i(double2 v) { return make_double2(v.y, -v.x); }
@@ -1835,7 +1837,8 @@ int launch(const PbsLaunch<T>& a, hipStream_t stream) {
   int dev = 0, cus = 0;
   CAMD_HIP(hipGetDevice(&dev));
   CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  if (wave_latency_enabled() && a.count <= (size_t)cus) {
+  constexpr int lat_fit = (int)((160 * 1024) / lat_lds_bytes<T, K, L>());
+  if (a.count <= wave_latency_limit(cus, lat_fit)) {
     constexpr size_t ldsl = lat_lds_bytes<T, K, L>();
     static_assert(ldsl <= 160 * 1024, "LDS budget exceeded");
     auto kernl = pbs_kernel_lat<T, K, L, BL>;
@@ -1866,11 +1869,12 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     return e ? atoi(e) : 2;
   }();
   // fewer ciphertexts than CUs: k+1 waves share each one
-  if (wave_latency_enabled()) {
+  {
     int dev = 0, cus = 0;
     CAMD_HIP(hipGetDevice(&dev));
     CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (a.count <= (size_t)cus) {
+    constexpr int lat_fit = (int)((160 * 1024) / wavelat_lds_bytes<T, K, L>());
+    if (a.count <= wave_latency_limit(cus, lat_fit)) {
       constexpr size_t ldsl = wavelat_lds_bytes<T, K, L>();
       static_assert(ldsl <= 160 * 1024, "LDS budget exceeded");
       auto kernl = wave_pbs_kernel_lat<T, K, L, BL>;
