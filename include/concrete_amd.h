@@ -63,11 +63,12 @@ typedef struct camd_params {
  * decryptions and the noise bound are the same, the last bits of a ciphertext may differ. AUTO
  * picks WAVE for the shortint sets that have an instance (N = 1024 with k = 2, N = 512 with k = 3)
  * and BLOCK otherwise; the WAVE instances for the two boolean parameter sets (32-bit torus:
- * N = 512, k = 2, two levels; N = 1024, k = 1, three levels) are selected by asking for them. A WAVE batch of at most one ciphertext per CU (two for N = 512) runs on a
- * variant that gives each ciphertext k+1 wavefronts: less than half the latency, same
- * decryptions; for N = 1024 the words may differ from those the same ciphertext gets inside a
- * large batch. The environment variable CAMD_WAVE_LATENCY=0 disables it (a positive value sets the
- * number of ciphertexts per CU up to which it is used). */
+ * N = 512, k = 2, two levels; N = 1024, k = 1, three levels) are selected by asking for them.
+ * A WAVE batch of at most one ciphertext per CU (two for N = 512) runs on a variant that gives
+ * each ciphertext k+1 wavefronts: less than half the latency, same decryptions; for the
+ * shortint N = 1024 sets the words may differ from those the same ciphertext gets inside a
+ * large batch. The environment variable CAMD_WAVE_LATENCY=0 disables it (a positive value sets
+ * the number of ciphertexts per CU up to which it is used). */
 #define CAMD_PBS_AUTO 0
 #define CAMD_PBS_GENERIC 1
 #define CAMD_PBS_WAVE 2
