@@ -7,13 +7,23 @@ ciphertexts per GPU, already resident in HBM. One "step" is one KS+PBS pass over
 With N > 1 every rank owns its own batch of 2^14 (weak scaling); the server key is built on
 rank 0 and broadcast once over RCCL; there is no collective in the timed region.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(`python -m torch.distributed.run ...` as a child process, before this process makes any GPU
+call) and exits with the child's status; started by a launcher (WORLD_SIZE set), --gpus must
+equal WORLD_SIZE. When there are more ranks than GPUs (a rehearsal on a one-GPU box) the ranks
+share the GPUs round-robin and the process group is gloo. `--plumbing` runs the multi-rank
+plumbing only (gloo, no GPU, no kernels: spawn, shards, key-blob broadcast, barriers, reduction).
+
 Prints one JSON line on rank 0 (see the keys below).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,22 +39,41 @@ from concrete_amd import client as CL  # noqa: E402
 from concrete_amd.backend import CAMD_PBS_AUTO, Context, DeviceServerKey  # noqa: E402
 from concrete_amd.shortint import ClientKey  # noqa: E402
 
-FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector peak (the FP64 matrix peak is the same figure)
+# MI355X FP64 vector rate: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz. This is the vendor's
+# datasheet figure (the FP64 matrix rate is the same number); the microarchitecture guide of this
+# image lists no FP64 row, so it is not a measured peak.
+FP64_PEAK_TFLOPS = 78.6
 SEED = 0xC0FFEE
 CPU_SAMPLE = 4096                # ciphertexts timed on the host cores (about 10 s on 16 threads)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "pmc_per_dispatch_final.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2", "pmc_per_dispatch_final.json")
+CSRC = os.path.join(ROOT, "concrete_amd", "csrc")
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: ties a committed counter summary to the code it measured."""
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes of this same
-    command (FETCH_SIZE and WRITE_SIZE cannot be read from inside the process). None when the
-    summary is absent."""
+    """(bytes per launch, provenance) of `kernel` from the committed rocprofv3 counter passes of
+    this same command (FETCH_SIZE and WRITE_SIZE cannot be read from inside the process). The
+    figure is only reported when the summary was taken from the kernel sources as they are now."""
     try:
         with open(PMC_SUMMARY) as f:
-            e = json.load(f)[kernel]
-        return float(e["hbm_fetch_bytes"] + e["hbm_write_bytes"])
+            doc = json.load(f)
+        e = doc[kernel]
+        prov = {"from_profile": os.path.relpath(PMC_SUMMARY, ROOT), "profile_source_hash": doc.get("source_hash"),
+                "source_hash": kernel_source_hash()}
+        if doc.get("source_hash") != prov["source_hash"]:
+            return None, dict(prov, stale=True)
+        return float(e["hbm_fetch_bytes"] + e["hbm_write_bytes"]), prov
     except (OSError, KeyError, ValueError):
-        return None
+        return None, {"from_profile": None}
 
 
 def flop_per_pbs(p) -> float:
@@ -111,19 +140,137 @@ OTHER_WORKLOADS = {
 }
 
 
+class Ranks:
+    """Rank layout of this process. `dist` is torch.distributed when a process group is up."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.backend = None
+        self.device_index = None
+        if args.plumbing:
+            self.backend = "gloo"
+        else:
+            ndev = torch.cuda.device_count()   # counting devices does not initialise the GPU
+            if ndev == 0:
+                raise SystemExit("bench.py: no GPU visible (use --plumbing for the CPU rehearsal of the rank plumbing)")
+            # more ranks than GPUs (rehearsal on a one-GPU box): ranks share GPUs, and RCCL refuses
+            # two ranks on one device, so the process group is gloo and the key travels via the host
+            self.device_index = self.local_rank % ndev
+            self.backend = "nccl" if self.world <= ndev else "gloo"
+            torch.cuda.set_device(self.device_index)
+        # CAMD_BENCH_FORCE_DIST=1 takes the multi-rank code path with a single rank
+        if self.world > 1 or os.environ.get("CAMD_BENCH_FORCE_DIST") == "1":
+            import torch.distributed as dist
+
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.device_index))
+            else:
+                dist.init_process_group(backend="gloo")
+            self.dist = dist
+
+    @property
+    def device(self):
+        return torch.device("cpu") if self.device_index is None else torch.device("cuda", self.device_index)
+
+    def sync(self) -> None:
+        if self.device_index is not None:
+            torch.cuda.synchronize()
+
+    def barrier_sync(self) -> None:
+        """barrier bracketed by device synchronisation, as the timing contract asks"""
+        self.sync()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x: int) -> int:
+        if self.dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=self.device if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+    def close(self) -> None:
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def spawn_ranks(args, argv) -> int:
+    """Start `args.gpus` ranks of this script under torch.distributed.run and wait for them. Runs in
+    a process that has made no GPU call; rank 0's JSON line reaches stdout through the inherited
+    descriptor."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1" if args.plumbing else env.get("OMP_NUM_THREADS", "16"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def plumbing(args) -> None:
+    """The multi-rank plumbing with no GPU: process group (gloo), index shards, one broadcast of a
+    key-sized blob, barriers around an empty timed region, max-reduce of the time. Checks that
+    `--gpus N` really runs N ranks; computes nothing, so `value` is null."""
+    from concrete_amd.distributed import broadcast_blob, shard_bounds
+
+    rk = Ranks(args)
+    count = args.batch
+    blob_bytes = 1 << 20   # stand-in for the 94.5 MB key blob
+    meta = torch.zeros(2, dtype=torch.int64)
+    blob = None
+    if rk.rank == 0:
+        meta[0], meta[1] = blob_bytes, 2
+        blob = torch.arange(blob_bytes, dtype=torch.int64).to(torch.uint8)
+    key_broadcast_ms = None
+    if rk.dist is not None:
+        rk.barrier_sync()
+        tb = time.perf_counter()
+        blob, meta = broadcast_blob(blob, meta, 0)
+        key_broadcast_ms = (time.perf_counter() - tb) * 1e3
+    checksum = int(blob.to(torch.int64).sum().item())
+    lo, hi = shard_bounds(count * rk.world, rk.world, rk.rank)
+    rk.barrier_sync()
+    t0 = time.perf_counter()
+    rk.barrier_sync()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0)
+    owned = rk.sum_over_ranks(hi - lo)
+    agree = rk.sum_over_ranks(int(checksum == int(torch.arange(blob_bytes, dtype=torch.int64).to(torch.uint8).to(torch.int64).sum())))
+    if rk.rank == 0:
+        print(json.dumps({
+            "metric": "bootstraps/sec (node), MESSAGE_2_CARRY_2", "value": None, "unit": "bootstraps/s",
+            "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "none",
+            "plumbing_only": True, "backend": rk.backend,
+            "config": {"workload": "rank plumbing only (PARAM_MESSAGE_2_CARRY_2 shards), no kernels",
+                       "batch_per_gpu": count, "global_batch": owned},
+            "ranks_with_identical_key_blob": agree, "key_broadcast_ms": key_broadcast_ms,
+            "barrier_region_ms": elapsed * 1e3}), flush=True)
+    rk.close()
+
+
 def other_workload(args) -> None:
     """Further configurations (largest polynomial size, boolean gates): same contract, random key
     material and random ciphertexts, so there is no decryption check and no CPU baseline."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist  # noqa: F811
-
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    rk = Ranks(args)
+    world, rank, dist = rk.world, rk.rank, rk.dist
     pname, default_batch, bits, order = OTHER_WORKLOADS[args.workload]
     p = getattr(P, pname)
     count = args.batch if args.batch != 1 << 14 else default_batch
@@ -134,19 +281,19 @@ def other_workload(args) -> None:
     def rnd(shape):
         return rs.randint(0, 2 ** 31, size=shape, dtype=np.int64).astype(dt) * dt(2)
 
-    ctx = Context(local_rank)
+    ctx = Context(rk.device_index)
     dk = None
     if rank == 0:
         dk = DeviceServerKey.from_standard_keys(ctx, p, rnd((n, L, k + 1, k + 1, N)), rnd((k * N, p.ks_level, n + 1)),
                                                 variant=args.variant, torus_bits=bits)
-    if world > 1:
+    if dist is not None:
         from concrete_amd.distributed import replicate_server_key
 
         dk = replicate_server_key(ctx, p, dk if rank == 0 else None, torus_bits=bits)
     lut = np.zeros((k + 1) * N, dtype=dt)
     lut[k * N:] = rnd(N)
     dk.upload_lut(lut)
-    device = torch.device("cuda", local_rank)
+    device = rk.device
     width = (k * N + 1) if order == "ks_pbs" else (n + 1)
     tdt = torch.int64 if bits == 64 else torch.int32
     cts = torch.randint(-2 ** 31, 2 ** 31 - 1, (count, width), dtype=torch.int64, device=device)
@@ -158,24 +305,14 @@ def other_workload(args) -> None:
         (lambda: dk.pbs_ks_device(cts, None, out, count, stream))
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    rk.barrier_sync()
     dk.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    rk.barrier_sync()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0)
     tm = dk.timing_read()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     if rank == 0:
         fpp = flop_per_pbs(p)
         achieved = count * fpp / (tm["pbs_ms"] * 1e-3) / 1e12 if tm["pbs_ms"] > 0 else 0.0
@@ -188,12 +325,12 @@ def other_workload(args) -> None:
                                    f"batch {count} per GPU, inputs resident in HBM",
                        "batch_per_gpu": count, "global_batch": count * world,
                        "pbs_kernel": {1: "generic", 2: "wave", 3: "block"}.get(dk.variant, str(dk.variant))},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flop_per_bootstrap": fpp,
-                         "kernel_ms": tm["pbs_ms"], "keyswitch_kernel_ms": tm["ks_ms"]},
+                         "kernel_ms": tm["pbs_ms"], "keyswitch_kernel_ms": tm["ks_ms"],
+                         "note": "peak is the vendor's FP64 vector figure; the guide of this image has no FP64 row"},
             "cpu_baseline": None}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    rk.close()
 
 
 def main() -> None:
@@ -204,35 +341,36 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=1 << 14, help="ciphertexts per GPU")
     ap.add_argument("--variant", type=int, default=CAMD_PBS_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-buffer-pass", action="store_true",
+                    help="skip the PCIe-inclusive pass (host buffers in, host buffers out) after the timed region")
     ap.add_argument("--luts", type=int, default=1, help="number of distinct look-up tables spread over the batch")
+    ap.add_argument("--plumbing", action="store_true",
+                    help="rank plumbing only, on the CPU with gloo: no GPU and no kernels (value is null)")
     ap.add_argument("--workload", default="2_2", choices=sorted(OTHER_WORKLOADS) + ["2_2"],
                     help="2_2 (default) is the headline configuration; the others time further configurations of the "
                          "same path with random key material (timing does not depend on the data)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # this process has made no GPU call: start the ranks as children and report their status
+            raise SystemExit(spawn_ranks(args, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={os.environ['WORLD_SIZE']} of the launcher")
+    if args.plumbing:
+        return plumbing(args)
     if args.workload != "2_2":
         return other_workload(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # CAMD_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL process group, key broadcast,
-    # barriers, max-reduce of the time) with a single rank: a rehearsal on a one-GPU box
-    use_dist = world > 1 or os.environ.get("CAMD_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        import torch.distributed as dist  # noqa: F811
-
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    rk = Ranks(args)
+    world, rank, dist = rk.world, rk.rank, rk.dist
+    device = rk.device
 
     p = P.PARAM_MESSAGE_2_CARRY_2
     count = args.batch
-    ctx = Context(local_rank)
-    cks = ClientKey(p, seed=SEED)  # secret keys only: cheap and identical on every rank
+    ctx = Context(rk.device_index)
+    cks = ClientKey(p, seed=SEED)  # secret keys only: cheap and identical on every rank (fixed test seed)
 
     # ---- server key: built on rank 0, broadcast once (Fourier BSK + KSK in one blob) ----
     bsk = ksk = None
@@ -242,14 +380,13 @@ def main() -> None:
         ksk = CL.gen_keyswitch_key(cks._rng, p, 64, cks.lwe_secret_key, cks.lwe_secret_key_after_ks)
         dk = DeviceServerKey.from_standard_keys(ctx, p, bsk, ksk, variant=args.variant)
     key_broadcast_ms = None
-    if use_dist:
+    if dist is not None:
         from concrete_amd.distributed import replicate_server_key
 
-        torch.cuda.synchronize()
-        dist.barrier()
+        rk.barrier_sync()
         tb = time.perf_counter()
         dk = replicate_server_key(ctx, p, dk if rank == 0 else None)
-        torch.cuda.synchronize()
+        rk.sync()
         key_broadcast_ms = (time.perf_counter() - tb) * 1e3
     key_setup_s = time.perf_counter() - t_key
 
@@ -274,37 +411,24 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    rk.barrier_sync()
     dk.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    rk.barrier_sync()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0)
     tm = dk.timing_read()
     dk.timing_enable(False)
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # ---- self-check: every output decrypts to f(m) ----
     got = decode_outputs(cks, out)
     expect = msgs % p.message_modulus
     if args.luts > 1:
         expect = (msgs + torch.arange(count, device=device) % args.luts) % p.message_modulus
-    wrong = int((got != expect).sum().item())
-    if dist is not None:
-        w = torch.tensor([wrong], dtype=torch.int64, device=device)
-        dist.all_reduce(w)
-        wrong = int(w.item())
+    bad = torch.nonzero(got != expect).flatten()
+    wrong_here = int(bad.numel())
+    wrong = rk.sum_over_ranks(wrong_here)
 
     if rank == 0:
         total = count * world * args.steps
@@ -312,6 +436,9 @@ def main() -> None:
         fpp = flop_per_pbs(p)
         pbs_s = tm["pbs_ms"] * 1e-3
         achieved = count * fpp / pbs_s / 1e12 if pbs_s > 0 else 0.0
+        traffic, provenance = (measured_traffic("wave_pbs_kernel") if dk.variant == 2 and count == 1 << 14
+                               else (None, {"from_profile": None}))
+        ks_macs = p.glwe_dimension * p.polynomial_size * p.ks_level * (p.lwe_dimension + 1)
         line = {
             "metric": "bootstraps/sec (node), MESSAGE_2_CARRY_2",
             "value": value,
@@ -331,23 +458,30 @@ def main() -> None:
                                                          f"{args.luts} look-up tables interleaved over the batch"),
                 "batch_per_gpu": count,
                 "global_batch": count * world,
-                "parallelism": f"batch sharded over {world} GPU(s); server key broadcast once, no per-step collective",
+                "parallelism": f"batch sharded over {world} rank(s), one per GPU; server key broadcast once "
+                               f"({rk.backend if dist is not None else 'no process group'}), no per-step collective",
                 "pbs_kernel": {1: "generic", 2: "wave", 3: "block"}.get(dk.variant, str(dk.variant)),
             },
             "roofline": {
-                "bound": "mfma",
+                "bound": "valu_fp64",
                 "achieved": achieved,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS,
-                "traffic": measured_traffic("wave_pbs_kernel") if dk.variant == 2 and count == 1 << 14 else None,
-                "traffic_unit": "bytes per launch past the L2 (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
-                                "profiles/r1/pmc_per_dispatch_final.json); the Fourier key is 56.7 MB",
+                "traffic": traffic,
+                "traffic_provenance": provenance,
+                "traffic_unit": "bytes per launch past the L2 (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, "
+                                "from the committed summary; null when the kernel sources changed since); the Fourier "
+                                "key is 56.7 MB and stays in the Infinity Cache, so this is fabric, not HBM, traffic",
                 "kernel": "programmable bootstrap (blind rotation), f64 on the vector ALUs",
                 "flop_per_bootstrap": fpp,
                 "kernel_ms": tm["pbs_ms"],
                 "keyswitch_kernel_ms": tm["ks_ms"],
-                "note": "peak is the MI355X FP64 vector rate; the FP64 matrix (MFMA) peak is the same 78.6 TFLOP/s",
+                "keyswitch_int_ops_per_s": (count * ks_macs / (tm["ks_ms"] * 1e-3)) if tm["ks_ms"] > 0 else None,
+                "note": "bound: f64 vector ALU (not the matrix cores: per frequency the contraction is a 3x3 complex "
+                        "matrix times one vector). peak = 78.6 TFLOP/s is the vendor's FP64 vector figure (256 CUs x 4 "
+                        "SIMDs x 16 FMA lanes x 2.4 GHz); the microarchitecture guide of this image has no FP64 row. "
+                        "keyswitch_int_ops_per_s counts wrapping u64 multiply-adds and is not part of the FP64 fraction",
             },
             # outputs that do not decrypt to f(m). The parameter set itself fails with probability
             # about 2^-13.9 per bootstrap (keyswitch + modulus-switch noise against the half box),
@@ -357,6 +491,17 @@ def main() -> None:
             "key_setup_s": key_setup_s,
             "key_broadcast_ms": key_broadcast_ms,
         }
+        if not args.no_host_buffer_pass:
+            # the same pass through the host-pointer entry point: pageable host buffers in and out,
+            # PCIe both ways inside the time. Reported beside `value`, never as `value`.
+            host_in = cts.cpu().numpy().view(np.uint64)
+            dk.ks_pbs(host_in[:2048], None if lut_ids is None else lut_ids[:2048].cpu().numpy())  # staging buffers, first touch
+            th = time.perf_counter()
+            host_out = dk.ks_pbs(host_in, None if lut_ids is None else lut_ids.cpu().numpy())
+            dth = time.perf_counter() - th
+            line["pcie_inclusive_value"] = count / dth
+            line["pcie_inclusive_ms_per_step"] = dth * 1e3
+            line["pcie_inclusive_matches_resident"] = bool(np.array_equal(host_out.view(np.int64), out.cpu().numpy()))
         if world == 1 and not args.no_cpu_baseline and args.luts == 1:
             cores = min(16, os.cpu_count() or 1)
             sample = cts[: min(count, CPU_SAMPLE)].cpu().numpy().view(np.uint64)
@@ -368,10 +513,27 @@ def main() -> None:
                                             "decrypt_mismatches": int((dec_cpu != dec_gpu).sum())}
         else:
             line["cpu_baseline"] = None
+        if not args.no_cpu_baseline and args.luts == 1:
+            # attribution of the ciphertexts that did not decrypt to f(m): the CPU restatement runs
+            # on exactly those inputs (rank 0's); a failure it shares is the parameter set's noise
+            # budget at work, one it does not share would be the GPU path's own
+            shared = None
+            if wrong_here:
+                from oracle import cpu_oracle as O
+
+                o = O.Oracle(p, 64)
+                fb = o.bsk_to_fourier(bsk)
+                idx = bad.cpu().numpy()
+                cpu_bad = o.ks_pbs_batch(ksk, fb, lut, None, cts[bad].cpu().numpy().view(np.uint64), threads=min(16, len(idx)))
+                dec = cks.decrypt_message_and_carry_batch(cpu_bad)
+                exp = expect[bad].cpu().numpy()
+                shared = int((dec != exp).sum())
+                line["failing_indices_rank0"] = [int(i) for i in idx[:16]]
+            line["failures_on_rank0"] = wrong_here
+            line["failures_shared_with_cpu"] = shared if wrong_here else 0
         print(json.dumps(line), flush=True)
 
-    if dist is not None:
-        dist.destroy_process_group()
+    rk.close()
 
 
 if __name__ == "__main__":

@@ -71,7 +71,8 @@ SYMBOLS = {
 
 
 class CamdRng(C.Structure):
-    _fields_ = [("s", C.c_uint64 * 4)]
+    _fields_ = [("s", C.c_uint64 * 4), ("counter", C.c_uint64), ("secure", C.c_uint32), ("have", C.c_uint32),
+                ("block", C.c_uint64 * 8)]
 
 
 _RP = C.POINTER(CamdRng)
@@ -79,6 +80,7 @@ _dbl, _u32, _u64 = C.c_double, C.c_uint32, C.c_uint64
 # every symbol include/concrete_amd_client.h declares
 SYMBOLS.update({
     "camd_rng_seed": (None, [_RP, _u64]),
+    "camd_rng_seed_secure": (_i, [_RP]),
     "camd_client_gen_binary_key": (_i, [_RP, _u32, _sz, _vp]),
     "camd_client_gen_bootstrap_key": (_i, [_RP, _PP, _dbl, _vp, _vp, _vp, _i]),
     "camd_client_gen_keyswitch_key": (_i, [_RP, _u32, _vp, _sz, _vp, _sz, _u32, _u32, _dbl, _vp]),

@@ -39,14 +39,14 @@ class Ciphertext:
 
 
 class ClientKey:
-    def __init__(self, parameters, seed: int = 0):
+    def __init__(self, parameters, seed: int | None = None):
         self.parameters = parameters
         self._rng = _client.Rng(seed)
         self.lwe_secret_key = _client.gen_binary_key(self._rng, 32, parameters.lwe_dimension)
         self.glwe_secret_key = _client.gen_binary_key(self._rng, 32, parameters.glwe_dimension * parameters.polynomial_size)
 
     @classmethod
-    def new(cls, parameters, seed: int = 0) -> "ClientKey":
+    def new(cls, parameters, seed: int | None = None) -> "ClientKey":
         return cls(parameters, seed)
 
     def encrypt(self, message: bool) -> Ciphertext:

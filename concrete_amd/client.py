@@ -1,7 +1,8 @@
 """Host-side client operations (keys, encryption, phase, look-up tables) over the C ABI of
 ``include/concrete_amd_client.h``. numpy in, numpy out; nothing here touches the GPU.
 
-The generator is a seedable xoshiro256**: deterministic, for tests and benchmarks, not a CSPRNG.
+``Rng()`` is ChaCha20 keyed from the operating system; ``Rng(seed)`` is a deterministic
+xoshiro256** sequence for tests and benchmarks and must not generate keys that protect data.
 """
 from __future__ import annotations
 
@@ -25,9 +26,16 @@ def _dtype(bits: int):
 
 
 class Rng:
-    def __init__(self, seed: int):
+    """``seed=None``: cryptographically secure (ChaCha20, key from getrandom). An integer seed gives
+    the reproducible test sequence."""
+
+    def __init__(self, seed: int | None = None):
         self.state = _ffi.CamdRng()
-        _ffi.lib().camd_rng_seed(C.byref(self.state), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF))
+        self.secure = seed is None
+        if seed is None:
+            check(_ffi.lib().camd_rng_seed_secure(C.byref(self.state)))
+        else:
+            _ffi.lib().camd_rng_seed(C.byref(self.state), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF))
 
 
 def gen_binary_key(rng: Rng, bits: int, length: int) -> np.ndarray:

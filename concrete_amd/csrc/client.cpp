@@ -4,6 +4,9 @@
 // DefaultEngine at concrete-shortint/src/engine/client_side.rs:9-144 and
 // concrete-shortint/src/engine/server_side/mod.rs:31-72.
 #pragma clang fp contract(off)
+#include <sys/random.h>
+
+#include <cerrno>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -26,7 +29,40 @@ inline uint64_t splitmix64(uint64_t& x) {
 }
 inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 
+// ChaCha20 block function (RFC 8439 quarter rounds; 64-bit block counter, zero nonce): the
+// secure mode of camd_rng. key = r.s, block number = r.counter, output = r.block.
+inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+inline void chacha_quarter(uint32_t* x, int a, int b, int c, int d) {
+  x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16);
+  x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12);
+  x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);
+  x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+}
+void chacha_refill(camd_rng& r) {
+  uint32_t in[16], x[16];
+  in[0] = 0x61707865u; in[1] = 0x3320646eu; in[2] = 0x79622d32u; in[3] = 0x6b206574u;
+  std::memcpy(in + 4, r.s, 32);
+  in[12] = (uint32_t)r.counter;
+  in[13] = (uint32_t)(r.counter >> 32);
+  in[14] = in[15] = 0;
+  std::memcpy(x, in, sizeof(x));
+  for (int round = 0; round < 10; round++) {
+    chacha_quarter(x, 0, 4, 8, 12); chacha_quarter(x, 1, 5, 9, 13);
+    chacha_quarter(x, 2, 6, 10, 14); chacha_quarter(x, 3, 7, 11, 15);
+    chacha_quarter(x, 0, 5, 10, 15); chacha_quarter(x, 1, 6, 11, 12);
+    chacha_quarter(x, 2, 7, 8, 13); chacha_quarter(x, 3, 4, 9, 14);
+  }
+  for (int i = 0; i < 16; i++) x[i] += in[i];
+  std::memcpy(r.block, x, 64);
+  r.counter++;
+  r.have = 8;
+}
+
 inline uint64_t next(camd_rng& r) {
+  if (r.secure) {
+    if (r.have == 0) chacha_refill(r);
+    return r.block[8 - r.have--];
+  }
   uint64_t* s = r.s;
   const uint64_t result = rotl(s[1] * 5, 7) * 9;
   const uint64_t t = s[1] << 17;
@@ -92,11 +128,24 @@ void lwe_encrypt_one(camd_rng& rng, const T* key, size_t dim, T pt, double std_d
   ct[dim] = acc + random_noise<T>(rng, std_dev) + pt;
 }
 
-template <typename T>
-void gen_ggsw(uint64_t seed, const camd_params& p, double std_dev, T bit, const T* glwe_key, T* out) {
-  const size_t k = p.glwe_dimension, N = p.polynomial_size;
+// A generator of the parent's kind for one worker: the deterministic kind is re-seeded from one
+// output word (what the tests' reference sequence does), the secure kind gets a fresh 256-bit
+// ChaCha20 key drawn from the parent's stream.
+camd_rng derive(camd_rng& parent) {
   camd_rng sub;
-  camd_rng_seed(&sub, seed);
+  if (parent.secure) {
+    std::memset(&sub, 0, sizeof(sub));
+    for (int i = 0; i < 4; i++) sub.s[i] = next(parent);
+    sub.secure = 1;
+  } else {
+    camd_rng_seed(&sub, next(parent));
+  }
+  return sub;
+}
+
+template <typename T>
+void gen_ggsw(camd_rng sub, const camd_params& p, double std_dev, T bit, const T* glwe_key, T* out) {
+  const size_t k = p.glwe_dimension, N = p.polynomial_size;
   for (uint32_t l = 1; l <= p.pbs_level; l++)
     for (size_t row = 0; row <= k; row++) {
       T* body = out + k * N;
@@ -121,8 +170,8 @@ void gen_bsk(camd_rng& rng, const camd_params& p, double std_dev, const T* lwe_k
              int threads) {
   const size_t n = p.lwe_dimension;
   const size_t per = (size_t)p.pbs_level * (p.glwe_dimension + 1) * (p.glwe_dimension + 1) * p.polynomial_size;
-  std::vector<uint64_t> seeds(n);
-  for (size_t i = 0; i < n; i++) seeds[i] = next(rng);
+  std::vector<camd_rng> seeds(n);
+  for (size_t i = 0; i < n; i++) seeds[i] = derive(rng);
   if (threads < 1) threads = 1;
   if ((size_t)threads > n) threads = (int)(n ? n : 1);
   std::vector<std::thread> pool;
@@ -151,8 +200,26 @@ bool bad_bits(uint32_t b) { return b != 32 && b != 64; }
 extern "C" {
 
 void camd_rng_seed(camd_rng* rng, uint64_t seed) {
+  std::memset(rng, 0, sizeof(*rng));
   uint64_t x = seed;
   for (int i = 0; i < 4; i++) rng->s[i] = splitmix64(x);
+}
+
+int camd_rng_seed_secure(camd_rng* rng) {
+  if (!rng) return camd::fail(CAMD_EINVAL, "rng_seed_secure: null generator");
+  std::memset(rng, 0, sizeof(*rng));
+  unsigned char* dst = (unsigned char*)rng->s;
+  size_t got = 0;
+  while (got < sizeof(rng->s)) {
+    const ssize_t r = getrandom(dst + got, sizeof(rng->s) - got, 0);
+    if (r < 0) {
+      if (errno == EINTR) continue;
+      return camd::fail(CAMD_EINVAL, std::string("rng_seed_secure: getrandom failed: ") + std::strerror(errno));
+    }
+    got += (size_t)r;
+  }
+  rng->secure = 1;
+  return CAMD_OK;
 }
 
 int camd_client_gen_binary_key(camd_rng* rng, uint32_t torus_bits, size_t len, void* key) {

@@ -44,6 +44,20 @@ def replicate_server_key(ctx, params, device_key, torus_bits: int = 64, src: int
 
     from .backend import DeviceServerKey
 
+    if dist.get_backend() != "nccl":
+        # no device-to-device transport (gloo: ranks that share a GPU, CPU rehearsals): the blob
+        # travels through host memory, still as one broadcast
+        meta = torch.zeros(2, dtype=torch.int64)
+        blob = None
+        if dist.get_rank() == src:
+            host = device_key.export_blob_host()
+            meta[0], meta[1] = host.size, device_key.variant
+            blob = torch.from_numpy(host)
+        blob, meta = broadcast_blob(blob, meta, src)
+        if dist.get_rank() == src:
+            return device_key
+        return DeviceServerKey.from_host_blob(ctx, params, blob.numpy(), int(meta[1].item()), torus_bits=torus_bits)
+
     device = torch.device("cuda", ctx.device_id)
     meta = torch.zeros(2, dtype=torch.int64, device=device)
     blob = None

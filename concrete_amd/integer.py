@@ -49,11 +49,11 @@ class RadixCiphertext:
 class ClientKey(CrtClientOps):
     """client_key/mod.rs:25-93 (the CRT entry points, :279-431, come from ``CrtClientOps``)."""
 
-    def __init__(self, parameters, seed: int = 0):
+    def __init__(self, parameters, seed: int | None = None):
         self.key = _si.ClientKey(parameters, seed)
 
     @classmethod
-    def new(cls, parameters, seed: int = 0) -> "ClientKey":
+    def new(cls, parameters, seed: int | None = None) -> "ClientKey":
         return cls(parameters, seed)
 
     @classmethod
@@ -126,7 +126,7 @@ class ClientKey(CrtClientOps):
 class RadixClientKey(ClientKey):
     """client_key/radix.rs: a client key that remembers the number of blocks."""
 
-    def __init__(self, parameters, num_blocks: int, seed: int = 0):
+    def __init__(self, parameters, num_blocks: int, seed: int | None = None):
         super().__init__(parameters, seed)
         self.num_blocks = int(num_blocks)
 

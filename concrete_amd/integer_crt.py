@@ -119,14 +119,14 @@ class CrtClientOps:
 class CrtClientKey:
     """client_key/crt.rs:6-43: an integer client key that remembers its CRT basis."""
 
-    def __init__(self, parameters, moduli: Iterable[int], seed: int = 0, key=None):
+    def __init__(self, parameters, moduli: Iterable[int], seed: int | None = None, key=None):
         from .integer import ClientKey
 
         self.key = key if key is not None else ClientKey(parameters, seed)
         self.moduli = [int(m) for m in moduli]
 
     @classmethod
-    def new(cls, parameters, moduli: Iterable[int], seed: int = 0) -> "CrtClientKey":
+    def new(cls, parameters, moduli: Iterable[int], seed: int | None = None) -> "CrtClientKey":
         return cls(parameters, moduli, seed)
 
     @classmethod

@@ -53,7 +53,7 @@ class FileStorage:
     def path(self, param) -> str:
         return os.path.join(self.prefix, param_name(param) + ".bin")
 
-    def load(self, param, ctx=None, seed: int = 0) -> Optional[SharedKey]:
+    def load(self, param, ctx=None, seed: int | None = None) -> Optional[SharedKey]:
         path = self.path(param)
         if not os.path.exists(path):
             return None
@@ -90,7 +90,7 @@ class KeyCache:
         self._memory: list = []
         self._lock = threading.Lock()
 
-    def get_from_param(self, param, ctx=None, seed: int = 0) -> SharedKey:
+    def get_from_param(self, param, ctx=None, seed: int | None = None) -> SharedKey:
         from . import shortint
         from .backend import Context
 

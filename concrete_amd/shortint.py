@@ -72,7 +72,7 @@ class LookupTable:
 class ClientKey:
     """Secret keys of one parameter set (engine/client_side.rs:9-31)."""
 
-    def __init__(self, parameters, seed: int = 0):
+    def __init__(self, parameters, seed: int | None = None):
         self.parameters = parameters
         self._rng = _client.Rng(seed)
         p = parameters
@@ -82,7 +82,7 @@ class ClientKey:
         self.lwe_secret_key = self.glwe_secret_key
 
     @classmethod
-    def new(cls, parameters, seed: int = 0) -> "ClientKey":
+    def new(cls, parameters, seed: int | None = None) -> "ClientKey":
         return cls(parameters, seed)
 
     @property

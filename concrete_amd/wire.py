@@ -329,7 +329,17 @@ def serialize_shortint_client_key(cks) -> bytes:
     return w.finish()
 
 
-def _read_shortint_client_key(r: Reader, seed: int):
+def _fresh_rng(seed):
+    """Generator of a key that was read back. The serialized form does not hold generator state,
+    and the sequence that produced the secret key must never be replayed into masks and noise
+    (its outputs ARE the key bits): without a seed the generator is keyed from the operating
+    system; a test seed is moved to a different sequence than key generation with that seed."""
+    from . import client as _client
+
+    return _client.Rng(None if seed is None else (int(seed) ^ 0x6C6F61646564206B) & 0xFFFFFFFFFFFFFFFF)
+
+
+def _read_shortint_client_key(r: Reader, seed):
     from . import client as _client
     from .shortint import ClientKey
 
@@ -343,15 +353,16 @@ def _read_shortint_client_key(r: Reader, seed: int):
         raise WireError("LWE secret keys do not match the parameter set")
     cks = ClientKey.__new__(ClientKey)
     cks.parameters = p
-    cks._rng = _client.Rng(seed)
+    cks._rng = _fresh_rng(seed)
     cks.lwe_secret_key_after_ks = after
     cks.glwe_secret_key = glwe
     cks.lwe_secret_key = lwe
     return cks
 
 
-def deserialize_shortint_client_key(data, seed: int = 0):
-    """``seed`` restarts the encryption noise generator, which is not part of the format."""
+def deserialize_shortint_client_key(data, seed: int | None = None):
+    """The encryption generator is not part of the format: it is keyed afresh from the operating
+    system; ``seed`` (tests only) gives a reproducible sequence distinct from key generation's."""
     r = Reader(data)
     cks = _read_shortint_client_key(r, seed)
     r.expect_end()
@@ -550,7 +561,7 @@ def serialize_boolean_client_key(cks) -> bytes:
     return w.finish()
 
 
-def deserialize_boolean_client_key(data, seed: int = 0):
+def deserialize_boolean_client_key(data, seed: int | None = None):
     from . import client as _client
     from .boolean import ClientKey
 
@@ -563,7 +574,7 @@ def deserialize_boolean_client_key(data, seed: int = 0):
         raise WireError("secret keys do not match the parameter set")
     cks = ClientKey.__new__(ClientKey)
     cks.parameters = p
-    cks._rng = _client.Rng(seed)
+    cks._rng = _fresh_rng(seed)
     cks.lwe_secret_key = lwe
     cks.glwe_secret_key = glwe
     return cks

@@ -4,10 +4,12 @@
  *
  * These mirror what the reference does on the client through concrete-core's DefaultEngine;
  * they exist so that a caller (tests, the benchmark, the host-side mirror of the reference
- * API) can produce the inputs of the GPU path. Randomness comes from a seedable xoshiro256**
- * generator: it is deterministic and NOT a cryptographically secure generator. A deployment
- * keeps concrete-core's own CSPRNG key generation and hands the resulting standard-domain
- * keys to camd_server_key_create.
+ * API) can produce the inputs of the GPU path. The generator has two kinds:
+ *   - camd_rng_seed_secure: ChaCha20 keyed with 256 bits from the operating system (getrandom);
+ *     secret keys, masks and noise of real keys come from this one, as the reference draws them
+ *     from concrete-csprng seeded by the OS (concrete-shortint/src/engine/mod.rs:15-31);
+ *   - camd_rng_seed: a seedable xoshiro256** sequence, deterministic and NOT cryptographically
+ *     secure: for tests and benchmarks that need reproducible keys, never for keys that protect data.
  *
  * Every function returns 0 on success, a negative CAMD_E* code otherwise.
  */
@@ -20,9 +22,18 @@
 extern "C" {
 #endif
 
-typedef struct camd_rng { uint64_t s[4]; } camd_rng;
+typedef struct camd_rng {
+  uint64_t s[4];      /* xoshiro256** state, or the ChaCha20 key of the secure kind */
+  uint64_t counter;   /* secure kind: number of the next 64-byte block */
+  uint32_t secure;    /* 0 = seeded deterministic sequence, 1 = ChaCha20 keyed from the OS */
+  uint32_t have;      /* secure kind: unread 64-bit words left in `block` */
+  uint64_t block[8];
+} camd_rng;
 
+/* deterministic sequence from a 64-bit seed: tests and benchmarks only */
 void camd_rng_seed(camd_rng* rng, uint64_t seed);
+/* ChaCha20 keyed with 256 bits of operating-system entropy */
+int camd_rng_seed_secure(camd_rng* rng);
 
 /* Uniform binary secret key of `len` words (each 0 or 1) in the torus width `torus_bits`.
  * Replaces generate_new_lwe_secret_key / generate_new_glwe_secret_key

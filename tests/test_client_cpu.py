@@ -45,3 +45,59 @@ def test_batches_decode_elementwise():
     assert cks.decrypt_without_padding(batch).tolist() == [0, 1, 3, 1]
     rows = np.stack([cks.encrypt_native_crt(m, 5).ct for m in (4, 0, 7)])
     assert cks.decrypt_message_native_crt(shortint.Ciphertext(rows, 4, 5, 1), 5).tolist() == [4, 0, 2]
+
+
+# ---- randomness: keys that protect data come from a CSPRNG keyed by the operating system ----
+
+def test_secure_generator_is_chacha20():
+    """Known answer: ChaCha20 with an all-zero key and nonce, block 0, starts 76 b8 e0 ad a0 f1 3d 90
+    (the classic test vector). Encrypting with a zero key and no noise exposes the mask words,
+    which are outputs 0 and 3 of the stream (two words go to the noise sample in between)."""
+    import ctypes as C
+
+    from concrete_amd import _ffi, client as CL
+
+    rng = CL.Rng(1)
+    C.memset(C.byref(rng.state), 0, C.sizeof(rng.state))
+    rng.state.secure = 1
+    cts = CL.lwe_encrypt(rng, 64, np.zeros(1, dtype=np.uint64), np.zeros(2, dtype=np.uint64), 0.0)
+    assert int(cts[0, 0]) == 0x903DF1A0ADE0B876
+    assert int(cts[1, 0]) == 0xC70D778BCCEF36A8
+
+
+def test_default_client_keys_are_fresh_and_seeded_ones_reproducible():
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    a, b = shortint.ClientKey.new(p), shortint.ClientKey.new(p)
+    assert not np.array_equal(a.glwe_secret_key, b.glwe_secret_key)
+    assert not np.array_equal(a.lwe_secret_key_after_ks, b.lwe_secret_key_after_ks)
+    assert set(np.unique(a.glwe_secret_key)) <= {0, 1}
+    assert 0.4 < a.glwe_secret_key.mean() < 0.6
+    s1, s2 = shortint.ClientKey.new(p, seed=7), shortint.ClientKey.new(p, seed=7)
+    assert np.array_equal(s1.glwe_secret_key, s2.glwe_secret_key)
+    # both kinds encrypt and decrypt
+    for cks in (a, s1):
+        for m in range(4):
+            assert cks.decrypt(cks.encrypt(m)) == m
+
+
+@pytest.mark.parametrize("seed", [None, 5])
+def test_masks_after_reload_carry_no_key_bits(seed):
+    """A key that is written out and read back must not replay the sequence that produced its
+    secret bits: with the old behaviour the top bit of mask word i of the first ciphertext after a
+    reload WAS bit i of the secret key."""
+    from concrete_amd import wire
+
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    cks = shortint.ClientKey.new(p, seed=seed)
+    back = wire.deserialize_shortint_client_key(wire.serialize_shortint_client_key(cks), seed=seed)
+    assert np.array_equal(back.glwe_secret_key, cks.glwe_secret_key)
+    ct = back.encrypt(1)
+    words = np.asarray(ct.ct if hasattr(ct, "ct") else ct, dtype=np.uint64).ravel()
+    n = p.lwe_dimension
+    top = (words[:n] >> np.uint64(63)).astype(np.int64)
+    agree = int((top == cks.lwe_secret_key_after_ks.astype(np.int64)).sum())
+    # independent bits agree about half the time (769 trials: 6 sigma is +-83)
+    assert abs(agree - n / 2) < 90, agree
+    top2 = (words[: 2 * 1024] >> np.uint64(63)).astype(np.int64)
+    agree2 = int((top2 == cks.glwe_secret_key.astype(np.int64)).sum())
+    assert abs(agree2 - 1024) < 140, agree2

@@ -179,6 +179,35 @@ def test_two_process_gloo_plumbing(tmp_path):
     assert res.stdout.count("ok") == 2
 
 
+def _bench(*argv, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                          timeout=300, env=e)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`bench.py --gpus 2` with no launcher around it starts two ranks itself (the CPU rehearsal
+    of the plumbing: gloo, no kernels) and rank 0 reports both."""
+    import json
+
+    r = _bench("--gpus", "2", "--plumbing", "--batch", "64")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128 and line["config"]["batch_per_gpu"] == 64
+    assert line["ranks_with_identical_key_blob"] == 2 and line["key_broadcast_ms"] is not None
+    assert line["plumbing_only"] is True and line["value"] is None
+
+
+def test_bench_rejects_a_gpus_flag_that_disagrees_with_the_launcher():
+    r = _bench("--gpus", "4", "--plumbing", env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
 def test_wave_kernel_keeps_parked_key_registers_untouched(tmp_path):
     """The wave kernel loads next iteration's key rows into accumulation registers with inline
     assembly, asynchronously: the compiler must never recycle or move those registers (a0..a223)
