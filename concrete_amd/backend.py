@@ -196,6 +196,11 @@ class DeviceServerKey:
     def reserve(self, count: int) -> None:
         check(_ffi.lib().camd_reserve(self._h, int(count)))
 
+    def check(self, stream: int = 0) -> None:
+        """Synchronise ``stream`` and raise if a device batch since the last check used a look-up
+        table id that is out of range (such ciphertexts were bootstrapped with table 0)."""
+        check(_ffi.lib().camd_server_key_check(self._h, C.c_void_p(stream)))
+
     def _dev(self, fn, ct_in, lut_ids, ct_out, count, stream, with_ids=True):
         ids_ptr = C.c_void_p(lut_ids.data_ptr()) if lut_ids is not None else None
         if with_ids:

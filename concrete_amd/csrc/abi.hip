@@ -99,8 +99,17 @@ struct camd_server_key {
   DeviceBuffer mid;         // keyswitch output (shortint order) or bootstrap output (boolean order)
   DeviceBuffer pbs_scratch;
   DeviceBuffer stage_in, stage_out, stage_ids;
-  std::mutex mu;
+  std::mutex mu;            // guards scratch, look-up tables, timing and the launch order of both kinds of entry point
   Timing timing;
+  // launch status word in pinned host memory, written by the kernels (kernels.hpp: STATUS_*)
+  uint32_t* status = nullptr;
+  // Device-pointer calls return while their kernels are still running on the caller's stream; they
+  // share `mid` and `pbs_scratch` with every other call on the key. The event marks the end of the
+  // last such call: a later call on another stream (the host-pointer entry points use the
+  // context's own) makes its stream wait for it before it touches the shared buffers.
+  hipEvent_t device_done = nullptr;
+  hipStream_t device_stream = nullptr;
+  bool device_pending = false;
   // host callers that arrive while a batch is on the GPU wait here and leave together, as one batch
   std::mutex queue_mu;
   std::condition_variable queue_cv;
@@ -181,6 +190,17 @@ int key_alloc(camd_context* ctx, const camd_params& p, int variant, camd_server_
     delete key;
     return fail(CAMD_ENOMEM, std::string("hipMalloc(key blob): ") + hipGetErrorString(e));
   }
+  e = hipHostMalloc((void**)&key->status, 64, hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *key->status = 0;
+    e = hipEventCreateWithFlags(&key->device_done, hipEventDisableTiming);
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(key->blob);
+    if (key->status) (void)hipHostFree(key->status);
+    delete key;
+    return fail(CAMD_EHIP, std::string("status word / event: ") + hipGetErrorString(e));
+  }
   const size_t tcount = (variant == CAMD_PBS_WAVE) ? wave_tables_count(p.polynomial_size) : generic_tables_count(p.polynomial_size);
   std::vector<double2> host(tcount);
   if (variant == CAMD_PBS_WAVE) wave_fill_tables(p.polynomial_size, host.data());
@@ -190,6 +210,8 @@ int key_alloc(camd_context* ctx, const camd_params& p, int variant, camd_server_
   if (e != hipSuccess) {
     (void)hipFree(key->blob);
     if (key->tables) (void)hipFree(key->tables);
+    (void)hipHostFree(key->status);
+    (void)hipEventDestroy(key->device_done);
     delete key;
     return fail(CAMD_EHIP, std::string("twiddle table upload: ") + hipGetErrorString(e));
   }
@@ -230,6 +252,8 @@ void key_free(camd_server_key* key) {
   key->timing.clear();
   if (key->blob) (void)hipFree(key->blob);
   if (key->tables) (void)hipFree(key->tables);
+  if (key->status) (void)hipHostFree(key->status);
+  if (key->device_done) (void)hipEventDestroy(key->device_done);
   key->luts.release();
   key->mid.release();
   key->pbs_scratch.release();
@@ -283,7 +307,7 @@ int run_pbs(camd_server_key* key, const T* in, size_t in_stride, const uint32_t*
   PbsLaunch<T> a{};
   a.ct_in = in; a.in_stride = in_stride; a.ct_out = out; a.out_stride = out_stride;
   a.lut_ids = ids; a.luts = (const T*)key->luts.ptr; a.lut_count = key->lut_count; a.count = count;
-  a.fbsk = key->fbsk(); a.tables = key->tables; a.scratch = key->pbs_scratch.ptr;
+  a.fbsk = key->fbsk(); a.tables = key->tables; a.scratch = key->pbs_scratch.ptr; a.status = key->status;
   a.n = p.lwe_dimension; a.k = p.glwe_dimension; a.N = p.polynomial_size; a.level = p.pbs_level; a.base_log = p.pbs_base_log;
   TimedRegion t(key, true, s);
   if (key->variant == CAMD_PBS_WAVE) return wave_launch_pbs<T>(a, s);
@@ -334,14 +358,41 @@ int run_op_device(camd_server_key* key, Op op, const void* in, const uint32_t* i
   return rc;
 }
 
+// A bad look-up table id seen by a kernel of an earlier device-pointer call (kernels.hpp:
+// checked_lut_id). The word is in host memory; it is certain to be up to date once the stream of
+// that call has been synchronised, and is looked at by every later call on the key.
+int report_status(camd_server_key* key) {
+  if (!key->status || *(volatile uint32_t*)key->status == 0) return CAMD_OK;
+  *(volatile uint32_t*)key->status = 0;
+  return fail(CAMD_EINVAL,
+              "an earlier device-pointer call on this key had a look-up table id out of range; those ciphertexts were "
+              "bootstrapped with table 0");
+}
+
+// makes `s` wait for the kernels of the last device-pointer call if they run on another stream
+int order_after_device_calls(camd_server_key* key, hipStream_t s) {
+  if (key->device_pending && key->device_stream != s) CAMD_HIP(hipStreamWaitEvent(s, key->device_done, 0));
+  return CAMD_OK;
+}
+
 int dispatch_device(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count, void* stream) {
   if (!key || (!in && count) || (!out && count)) return fail(CAMD_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lock(key->mu);
+  int rc = report_status(key);
+  if (rc != CAMD_OK) return rc;
   if (count == 0) return CAMD_OK;
   DeviceGuard g(key->ctx->device);
   if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
   hipStream_t s = (hipStream_t)stream;
-  return key->p.torus_bits == 64 ? run_op_device<uint64_t>(key, op, in, ids, out, count, s)
-                                 : run_op_device<uint32_t>(key, op, in, ids, out, count, s);
+  rc = order_after_device_calls(key, s);
+  if (rc != CAMD_OK) return rc;
+  rc = key->p.torus_bits == 64 ? run_op_device<uint64_t>(key, op, in, ids, out, count, s)
+                               : run_op_device<uint32_t>(key, op, in, ids, out, count, s);
+  // recorded even after a failed launch sequence: whatever was enqueued must be waited for
+  CAMD_HIP(hipEventRecord(key->device_done, s));
+  key->device_stream = s;
+  key->device_pending = true;
+  return rc;
 }
 
 // Ciphertexts per slice of a host-buffer batch: the copies of one slice run beside the kernels
@@ -481,11 +532,26 @@ int serve_many(camd_server_key* key, Op op, const std::vector<HostRequest*>& gro
 void serve(camd_server_key* key, Op op, std::vector<HostRequest*>& group) {
   std::lock_guard<std::mutex> lock(key->mu);
   DeviceGuard g(key->ctx->device);
+  // kernels of an earlier device-pointer call may still be running on the caller's stream with
+  // the shared scratch: the context's stream waits for them; this call ends synchronised, so the
+  // reverse order needs nothing
+  int order_rc = g.ok ? order_after_device_calls(key, key->ctx->stream) : CAMD_OK;
+  if (order_rc == CAMD_OK && g.ok && key->device_pending) {
+    // the status word of those calls is final once their stream has drained
+    if (hipEventSynchronize(key->device_done) == hipSuccess) key->device_pending = false;
+    order_rc = report_status(key);
+  }
+  const std::string order_err = g_last_error;
   std::vector<HostRequest*> good;
   for (HostRequest* r : group) {
     if (!g.ok) {
       r->rc = CAMD_EHIP;
       r->err = "hipSetDevice failed";
+      continue;
+    }
+    if (order_rc != CAMD_OK) {
+      r->rc = order_rc;
+      r->err = order_err;
       continue;
     }
     bool ids_ok = true;
@@ -733,6 +799,16 @@ int camd_pbs_batch(camd_server_key* key, const void* ct_in, const uint32_t* lut_
 }
 int camd_ks_batch(camd_server_key* key, const void* ct_in, void* ct_out, size_t count) {
   return dispatch_host(key, Op::Ks, ct_in, nullptr, ct_out, count);
+}
+
+int camd_server_key_check(camd_server_key* key, void* stream) {
+  if (!key) return fail(CAMD_EINVAL, "null key");
+  std::lock_guard<std::mutex> lock(key->mu);
+  DeviceGuard g(key->ctx->device);
+  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
+  CAMD_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (key->device_pending && key->device_stream == (hipStream_t)stream) key->device_pending = false;
+  return report_status(key);
 }
 
 int camd_reserve(camd_server_key* key, size_t count) {

@@ -21,8 +21,24 @@ struct PbsLaunch {
   const double2* fbsk;       // Fourier bootstrap key in the layout of the kernel family
   const double2* tables;     // twiddle tables of the kernel family
   void* scratch;             // per-workgroup scratch (generic and block families), arrival counters (wave family)
+  uint32_t* status;          // launch status word in host-visible memory (bit 0: a look-up table id was out of range)
   uint32_t n, k, N, level, base_log;
 };
+
+constexpr uint32_t STATUS_BAD_LUT_ID = 1u;
+
+// Look-up table of ciphertext `ct`. The host-pointer entry points reject an id that is out of range
+// before anything is launched; a device-pointer call cannot look at its ids without a round trip,
+// so the kernel checks: a bad id raises STATUS_BAD_LUT_ID in the key's status word (the next call
+// on the key reports it as CAMD_EINVAL) and the ciphertext is bootstrapped with table 0 so that
+// every access stays in bounds.
+template <typename T>
+__device__ __forceinline__ uint32_t checked_lut_id(const PbsLaunch<T>& a, size_t ct) {
+  const uint32_t id = a.lut_ids ? a.lut_ids[ct] : 0u;
+  if (id < a.lut_count) return id;
+  *(volatile uint32_t*)a.status = STATUS_BAD_LUT_ID;
+  return 0u;
+}
 
 // ---- keyswitch (keyswitch.hip) ----
 template <typename T>

@@ -316,8 +316,8 @@ void block_pbs_kernel(PbsLaunch<T> a) {
 
   for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
     const T* in = a.ct_in + ct * a.in_stride;
-    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
-    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * G;
+    const uint32_t lut_id = checked_lut_id(a, ct);
+    const T* lut = a.luts + (size_t)lut_id * G;
 
     // ct0 <- lut * X^{-b_hat}
     const uint32_t b_hat = modswitch<T>(in[n], logN);

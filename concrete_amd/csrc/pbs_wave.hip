@@ -25,12 +25,6 @@
 
 #include "kernels.hpp"
 
-// CAMD_ABLATE is a debug aid for timing experiments (results are wrong when it is set):
-//   1 = no lane exchanges, 2 = no key-row loads, 3 = no accumulator update, 4 = no rotation gather
-#ifndef CAMD_ABLATE
-#define CAMD_ABLATE 0
-#endif
-
 namespace camd {
 
 namespace {
@@ -110,7 +104,6 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
 #pragma unroll
   for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
   // exchange 1: register index b <-> lane bits 5:3
-#if CAMD_ABLATE != 1
 #pragma unroll
   for (int b = 0; b < 8; b++) {
     sre[b * ROW + lane] = x[b].x; sim[b * ROW + lane] = x[b].y;
@@ -120,12 +113,10 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
     const int idx = hi * ROW + q * 8 + lo;
     x[q] = make_double2(sre[idx], sim[idx]);
   }
-#endif
   dft8<false>(x);
 #pragma unroll
   for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW1 + (b - 1) * 8 + lo]);
   // exchange 2: register index b' <-> lane bits 2:0 (XOR keeps both sides conflict-free)
-#if CAMD_ABLATE != 1
 #pragma unroll
   for (int b = 0; b < 8; b++) {
     const int idx = hi * ROW + b * 8 + (lo ^ b);
@@ -136,7 +127,6 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
     const int idx = hi * ROW + lo * 8 + (q ^ lo);
     x[q] = make_double2(sre[idx], sim[idx]);
   }
-#endif
   dft8<false>(x);
 }
 
@@ -145,7 +135,6 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
                                                double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
   dft8<true>(x);
-#if CAMD_ABLATE != 1
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + lo * 8 + (q ^ lo);
@@ -156,11 +145,9 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
     const int idx = hi * ROW + b * 8 + (lo ^ b);
     x[b] = make_double2(sre[idx], sim[idx]);
   }
-#endif
 #pragma unroll
   for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW1 + (b - 1) * 8 + lo]);
   dft8<true>(x);
-#if CAMD_ABLATE != 1
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + q * 8 + lo;
@@ -168,7 +155,6 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
   }
 #pragma unroll
   for (int b = 0; b < 8; b++) x[b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
-#endif
 #pragma unroll
   for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
   dft8<true>(x);
@@ -364,8 +350,8 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
 
   const T* in = a.ct_in + ct * a.in_stride;
   const uint32_t n = a.n;
-  const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
-  const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * ((K + 1) * N);
+  const uint32_t lut_id = checked_lut_id(a, ct);
+  const T* lut = a.luts + (size_t)lut_id * ((K + 1) * N);
 
   // ct0 <- lut * X^{-b_hat}
   {
@@ -384,20 +370,12 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
   // does; their rows are never loaded.
   double2 bq[K + 1][8];
   auto load_rows = [&](uint32_t it, int r, int l) {
-#if CAMD_ABLATE == 5
-    const double2* brow = a.fbsk + ((((size_t)(it & 3) * L + (l - 1)) * (K + 1) + r) * (K + 1)) * M + lane;
-#else
     const double2* brow = a.fbsk + ((((size_t)it * L + (l - 1)) * (K + 1) + r) * (K + 1)) * M + lane;
-#endif
 #pragma unroll
     for (int c = 0; c <= K; c++)
 #pragma unroll
       for (int g = 0; g < 8; g++) {
-#if CAMD_ABLATE == 2
-        bq[c][g] = make_double2(1e-3 * (double)(uintptr_t)brow, 2e-3);
-#else
         bq[c][g] = brow[(size_t)c * M + g * 64];
-#endif
       }
   };
   double2 acc[K + 1][8];
@@ -425,13 +403,8 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-#if CAMD_ABLATE == 4
-        const T x0 = (T)(j0 * 0x9E3779B97F4A7C15ull + a_hat), x1 = (T)(j1 * 0xBF58476D1CE4E5B9ull + a_hat);
-        (void)p;
-#else
         const T x0 = rotated_coeff<T>(p, j0, a_hat, N) - p[j0];
         const T x1 = rotated_coeff<T>(p, j1, a_hat, N) - p[j1];
-#endif
         st0[q] = digit_state32<T, BL, L>(x0);
         st1[q] = digit_state32<T, BL, L>(x1);
       }
@@ -484,12 +457,8 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
         for (int q = 0; q < 8; q++) {
           const uint32_t j0 = 64 * q + lane;
           const double2 v = cmul_conj(z[q], tab[TAB_TWIST + j0]);
-#if CAMD_ABLATE == 3
-          asm volatile("" ::"v"(v.x), "v"(v.y));
-#else
           pc[j0] = torus_accumulate(pc[j0], v.x);
           pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
-#endif
         }
       }
     }
@@ -634,8 +603,41 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
 // a wave moves on once all but 1/8 of its XCD's waves have arrived: waiting for the very last
 // straggler costs 1.5 % of the run, this costs nothing and keeps the fetch traffic at its minimum
 constexpr uint32_t WAVE_QUORUM_SLACK = 8;
-constexpr int SYNC_GROUPS = 8;          // one arrival counter per XCD
+constexpr int SYNC_GROUPS = 16;         // the hardware's XCC id is a 4-bit field (MI355X has 8 XCDs)
 constexpr int SYNC_STRIDE = 32;         // counters 128 bytes apart
+
+// Rendezvous of the persistent waves that share an L2. Nothing is assumed about how workgroups are
+// dealt to XCDs or how many XCDs there are: every wave reads the id of the XCD it runs on from the
+// hardware register, enrols in that XCD's member count when it starts, and between ciphertexts
+// reports to that XCD's arrival counter and waits until all but 1/WAVE_QUORUM_SLACK of the members
+// have arrived. The first wait comes a whole bootstrap (milliseconds) after the launch, when every
+// workgroup of the device-sized grid has long enrolled; should a member count still be short, or a
+// wave lag, the wait is bounded and only cache behaviour is affected, never results.
+// Both counter arrays live in the key's scratch buffer and are cleared by every launch.
+struct XcdRendezvous {
+  uint32_t* arrivals;
+  uint32_t* members;
+  __device__ __forceinline__ void enrol(void* scratch, int lane) {
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): register 20, offset 0, width 4
+    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (SYNC_GROUPS - 1);
+    arrivals = (uint32_t*)scratch + xcc * SYNC_STRIDE;
+    members = arrivals + SYNC_GROUPS * SYNC_STRIDE;
+    if (lane == 0) __hip_atomic_fetch_add(members, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // after ciphertext number `round` (0-based) of this wave
+  __device__ __forceinline__ void arrive_and_wait(uint32_t round, int lane) {
+    if (lane == 0) {
+      __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t m = __hip_atomic_load(members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t target = (round + 1) * m - m / WAVE_QUORUM_SLACK;
+      for (uint32_t spin = 0; spin < (1u << 16); spin++) {
+        if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+};
 template <typename T, int K, int BL>
 __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1;
@@ -660,16 +662,15 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   // after each ciphertext a wave reports to its XCD's counter and waits until all of them have.
   // Without this the waves drift apart by more key rows than the 4 MB L2 holds within a few
   // ciphertexts, and each row is fetched from the fabric many times per XCD.
-  const uint32_t group = blockIdx.x % SYNC_GROUPS;
-  const uint32_t group_waves = ((gridDim.x - group + SYNC_GROUPS - 1) / SYNC_GROUPS) * WAVES;
-  uint32_t* arrivals = (uint32_t*)a.scratch + group * SYNC_STRIDE;
+  XcdRendezvous rendezvous;
+  if (a.scratch) rendezvous.enrol(a.scratch, lane);
   const size_t per_round = (size_t)gridDim.x * WAVES;
   uint32_t round = 0;
   for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round, round++) {
   const T* in = a.ct_in + ct * a.in_stride;
   const uint32_t n = a.n;
-  const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
-  const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N);
+  const uint32_t lut_id = checked_lut_id(a, ct);
+  const T* lut = a.luts + (size_t)lut_id * (R * N);
   {
     const uint32_t b_hat = modswitch<T>(in[n], LOGN);
     const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
@@ -964,223 +965,14 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   // rendezvous, only when a further round follows (this one was then a full round); the
   // wait is bounded so that a wave can never be held forever (the order of work does not
   // affect results, only cache behaviour)
-  if ((size_t)(round + 1) * per_round < a.count) {
-    if (lane == 0) {
-      __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t target = (round + 1) * group_waves - group_waves / WAVE_QUORUM_SLACK;
-      for (uint32_t spin = 0; spin < (1u << 16); spin++) {
-        if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-        __builtin_amdgcn_s_sleep(16);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+  if ((size_t)(round + 1) * per_round < a.count) rendezvous.arrive_and_wait(round, lane);
   }
 }
 
-// ---- the bootstrap, third schedule: two waves per SIMD ----
-// The second schedule is held at one wave per SIMD by LDS (24 KB of accumulator per ciphertext)
-// and by the 288 registers of parked key rows. Here the accumulator lives in registers
-// ((k+1) x 16 torus words per lane), the rotation goes through an 8 KB per-wave staging row, and
-// key rows are ordinary loads consumed where they land: a wave needs 17.4 KB of LDS and at most
-// 256 registers, so eight waves (512 threads) share a CU and each SIMD always has a second wave
-// to issue from while the first waits on LDS, memory or a dependent result. No inline-assembly
-// loads: every wait is placed by the compiler. The multiply-accumulate works in place, one
-// frequency register at a time (its k+1 inputs are consumed to produce its k+1 outputs).
-//
-// Measured: 121-124 ms per 2^14 bootstraps against 119 ms for the second schedule, so this one is
-// not the default (CAMD_WAVE_SCHEDULE=3 selects it). With 256 registers per wave there is room
-// for three steps of key prefetch (36 products) against an L2 latency of several hundred cycles,
-// and the compiler still spills some forty registers whose reloads wait behind the key loads;
-// the vector ALU of a SIMD is busy 60 % of the time with its two waves. Parking a whole
-// iteration of key rows, as the second schedule does, needs the 288 registers only a lone wave has.
-constexpr int WAVES3 = 8;
-#ifndef WAVE3_KEY_AHEAD
-#define WAVE3_KEY_AHEAD 3
-#endif
-
+// per-wave LDS of the k+1-wave variant: exchange image + one staging row for the rotation
 template <typename T, int K>
-constexpr size_t wave3_slab_bytes() {
+constexpr size_t lat_slab_bytes() {
   return 2 * PLANE * sizeof(double) + 1024 * sizeof(T);
-}
-template <typename T, int K>
-constexpr size_t wave3_lds_bytes() {
-  return TAB_COUNT * sizeof(double2) + WAVES3 * wave3_slab_bytes<T, K>();
-}
-
-template <typename T, int K, int BL>
-__global__ __launch_bounds__(64 * WAVES3) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void wave_pbs_kernel_v3(PbsLaunch<T> a) {
-  constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1, NS = R * R;
-  extern __shared__ __align__(16) char smem[];
-  double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * WAVES3) tab[t] = a.tables[t];
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * wave3_slab_bytes<T, K>();
-  double* sre = (double*)slab;
-  double* sim = sre + PLANE;
-  T* stage = (T*)(slab + 2 * PLANE * sizeof(double));
-  const uint32_t n = a.n;
-
-  // persistent waves with a per-XCD quorum rendezvous between ciphertexts (see the second schedule)
-  const uint32_t group = blockIdx.x % SYNC_GROUPS;
-  const uint32_t group_waves = ((gridDim.x - group + SYNC_GROUPS - 1) / SYNC_GROUPS) * WAVES3;
-  uint32_t* arrivals = (uint32_t*)a.scratch + group * SYNC_STRIDE;
-  const size_t per_round = (size_t)gridDim.x * WAVES3;
-  uint32_t round = 0;
-  for (size_t ct = (size_t)blockIdx.x * WAVES3 + wave; ct < a.count; ct += per_round, round++) {
-    const T* in = a.ct_in + ct * a.in_stride;
-    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
-    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N);
-
-    // accumulator: acc[c][2q] = coefficient 64q + lane, acc[c][2q+1] = coefficient 64q + lane + N/2
-    T acc[R][16];
-    {
-      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
-      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
-#pragma unroll
-      for (int c = 0; c < R; c++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          acc[c][2 * q] = rotated_coeff<T>(lut + (size_t)c * N, 64 * q + lane, d0, N);
-          acc[c][2 * q + 1] = rotated_coeff<T>(lut + (size_t)c * N, 64 * q + lane + M, d0, N);
-        }
-    }
-
-    T a_next = wave_uniform(in[0]);
-    for (uint32_t i = 0; i < n; i++) {
-      const T a_cur = a_next;
-      a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
-      if (a_cur == 0) continue;           // the reference skips these too
-      const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
-      // opaque copy of the lane index: LDS and table addresses are recomputed per iteration (one
-      // add each) instead of being hoisted out of the loop, where they would crowd out the
-      // accumulator and be spilled
-      int lane_i = lane;
-      asm volatile("" : "+v"(lane_i));
-#define lane lane_i
-
-      double2 x[R][8];
-      int32_t dg[R][16];  // digits wait as integers (half the registers) until their transform starts
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        // rotation by X^a_hat: the polynomial is laid out once in the staging row and read back
-        // at the rotated index (the wave's LDS operations complete in order)
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          stage[64 * q + lane] = acc[r][2 * q];
-          stage[64 * q + lane + M] = acc[r][2 * q + 1];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-          const T v0 = stage[(j0 - a_hat) & (N - 1)], v1 = stage[(j1 - a_hat) & (N - 1)];
-          const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - v0) : v0;
-          const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - v1) : v1;
-          uint32_t s0 = digit_state32<T, BL, L>((T)(r0 - acc[r][2 * q]));
-          uint32_t s1 = digit_state32<T, BL, L>((T)(r1 - acc[r][2 * q + 1]));
-          dg[r][2 * q] = digit_next32<BL, L>(s0);
-          dg[r][2 * q + 1] = digit_next32<BL, L>(s1);
-          if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // at most two points' reads in flight
-        }
-      }
-      // one transform after the other: with a second wave on the SIMD, interleaving the streams
-      // buys nothing and costs the registers the accumulator needs
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-          x[r][q] = cmul(make_double2((double)dg[r][2 * q], (double)dg[r][2 * q + 1]), tab[TAB_TWIST + 64 * q + lane]);
-        fft512_forward(x[r], lane, tab, sre, sim);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-
-      // x[c][g] <- sum_r key[r][c][g] * x[r][g], one frequency register at a time
-      const double2* key = a.fbsk + (size_t)i * NS * M + lane;
-      // flattened over (register g, output column c): the k+1 key values of step t+1 are
-      // requested before the products of step t, so 2(k+1) complex values are in flight instead
-      // of whole rows; the fences keep the compiler from hoisting all 72 loads and spilling the
-      // accumulator to make room
-      constexpr int AHEAD = WAVE3_KEY_AHEAD;  // steps of key values in flight ahead of the products
-      double2 kk[AHEAD + 1][R];
-      auto issue_keys = [&](int t) {
-        const int g = t / R, c = t % R;
-#pragma unroll
-        for (int r = 0; r < R; r++) kk[t % (AHEAD + 1)][r] = key[(size_t)(r * R + c) * M + g * 64];
-      };
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < AHEAD; t++) issue_keys(t);
-      double2 in_g[R];
-#pragma unroll
-      for (int t = 0; t < 8 * R; t++) {
-        const int g = t / R, c = t % R;
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + AHEAD < 8 * R) issue_keys(t + AHEAD);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c == 0) {
-#pragma unroll
-          for (int r = 0; r < R; r++) in_g[r] = x[r][g];
-        }
-        double2 v = cmul(kk[t % (AHEAD + 1)][0], in_g[0]);
-#pragma unroll
-        for (int r = 1; r < R; r++) v = cfma(kk[t % (AHEAD + 1)][r], in_g[r], v);
-        x[c][g] = v;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int c = 0; c < R; c++) {
-        __builtin_amdgcn_sched_barrier(0);
-        fft512_inverse(x[c], lane, tab, sre, sim);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // The staging row still holds the last polynomial exactly as the gather laid it out: its
-      // registers are free during the transforms and the multiply-accumulate, and it is read
-      // back here (32 fewer live registers where the pressure peaks).
-#pragma unroll
-      for (int c = 0; c < R; c++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          if (c == R - 1) {
-            acc[c][2 * q] = stage[64 * q + lane];
-            acc[c][2 * q + 1] = stage[64 * q + lane + M];
-          }
-          const double2 v = cmul_conj(x[c][q], tab[TAB_TWIST + 64 * q + lane]);
-          acc[c][2 * q] = torus_accumulate(acc[c][2 * q], v.x);
-          acc[c][2 * q + 1] = torus_accumulate(acc[c][2 * q + 1], v.y);
-          if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-#undef lane
-    }
-
-    // sample extraction of coefficient 0: out[c N + (N - j) mod N] = (j == 0) ? p[j] : -p[j]
-    T* out = a.ct_out + ct * a.out_stride;
-#pragma unroll
-    for (int c = 0; c < K; c++)
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-        out[(size_t)c * N + ((N - j0) & (N - 1))] = (j0 == 0) ? acc[c][2 * q] : (T)(T(0) - acc[c][2 * q]);
-        out[(size_t)c * N + (N - j1)] = (T)(T(0) - acc[c][2 * q + 1]);
-      }
-    if (lane == 0) out[K * N] = acc[K][0];
-
-    if ((size_t)(round + 1) * per_round < a.count) {
-      if (lane == 0) {
-        __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t target = (round + 1) * group_waves - group_waves / WAVE_QUORUM_SLACK;
-        for (uint32_t spin = 0; spin < (1u << 16); spin++) {
-          if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-          __builtin_amdgcn_s_sleep(16);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
 }
 
 // ---- the bootstrap, latency schedule: k+1 waves per ciphertext ----
@@ -1196,7 +988,7 @@ void wave_pbs_kernel_v3(PbsLaunch<T> a) {
 // Same products in the same order as the third schedule, hence the same ciphertext words.
 template <typename T, int K, int L>
 constexpr size_t wavelat_lds_bytes() {
-  return TAB_COUNT * sizeof(double2) + (K + 1) * wave3_slab_bytes<T, K>() + 2 * (size_t)(K + 1) * L * 512 * sizeof(double2);
+  return TAB_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T, K>() + 2 * (size_t)(K + 1) * L * 512 * sizeof(double2);
 }
 
 template <typename T, int K, int L, int BL>
@@ -1209,18 +1001,18 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = the polynomial this wave owns
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * wave3_slab_bytes<T, K>();
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T, K>();
   double* sre = (double*)slab;
   double* sim = sre + PLANE;
   T* stage = (T*)(slab + 2 * PLANE * sizeof(double));
-  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * wave3_slab_bytes<T, K>());  // [2][S][8][64]
+  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T, K>());  // [2][S][8][64]
   const uint32_t n = a.n;
   uint32_t image = 0;
 
   for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
     const T* in = a.ct_in + ct * a.in_stride;
-    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
-    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N) + (size_t)wave * N;
+    const uint32_t lut_id = checked_lut_id(a, ct);
+    const T* lut = a.luts + (size_t)lut_id * (R * N) + (size_t)wave * N;
 
     // acc[2q] = coefficient 64q + lane, acc[2q+1] = coefficient 64q + lane + N/2 of the own polynomial
     T acc[16];
@@ -1508,16 +1300,15 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
   const uint32_t lane_off = (uint32_t)lane * 16u;
   // persistent waves restart together per XCD (see wave_pbs_kernel_v2): key rows are then fetched
   // into each L2 once instead of once per drifting wave
-  const uint32_t group = blockIdx.x % SYNC_GROUPS;
-  const uint32_t group_waves = ((gridDim.x - group + SYNC_GROUPS - 1) / SYNC_GROUPS) * WAVES;
-  uint32_t* arrivals = (uint32_t*)a.scratch + group * SYNC_STRIDE;
+  XcdRendezvous rendezvous;
+  if (a.scratch) rendezvous.enrol(a.scratch, lane);
   const size_t per_round = (size_t)gridDim.x * WAVES;
   uint32_t round = 0;
   for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round, round++) {
     const T* in = a.ct_in + ct * a.in_stride;
     const uint32_t n = a.n;
-    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
-    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N);
+    const uint32_t lut_id = checked_lut_id(a, ct);
+    const T* lut = a.luts + (size_t)lut_id * (R * N);
     {
       const uint32_t b_hat = modswitch<T>(in[n], LOGN);
       const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
@@ -1659,17 +1450,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
       out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
     }
     if (lane == 0) out[K * N] = ct0[K * N];
-    if ((size_t)(round + 1) * per_round < a.count) {
-      if (lane == 0) {
-        __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t target = (round + 1) * group_waves - group_waves / WAVE_QUORUM_SLACK;
-        for (uint32_t spin = 0; spin < (1u << 16); spin++) {
-          if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-          __builtin_amdgcn_s_sleep(16);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
+    if ((size_t)(round + 1) * per_round < a.count) rendezvous.arrive_and_wait(round, lane);
   }
 }
 
@@ -1703,8 +1484,8 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
 
   for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
     const T* in = a.ct_in + ct * a.in_stride;
-    const uint32_t lut_id = a.lut_ids ? a.lut_ids[ct] : 0u;
-    const T* lut = a.luts + (size_t)(lut_id < a.lut_count ? lut_id : 0u) * (R * N) + (size_t)wave * N;
+    const uint32_t lut_id = checked_lut_id(a, ct);
+    const T* lut = a.luts + (size_t)lut_id * (R * N) + (size_t)wave * N;
     // acc[2q] = coefficient 64q + lane, acc[2q+1] = coefficient 64q + lane + N/2 of the own polynomial
     T acc[8];
     {
@@ -1885,24 +1666,6 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     }
   }
   if constexpr (L == 1) {
-    if (schedule == 3) {
-      constexpr size_t lds3 = wave3_lds_bytes<T, K>();
-      static_assert(lds3 <= 160 * 1024, "LDS budget exceeded");
-      auto kern3 = wave_pbs_kernel_v3<T, K, BL>;
-      CAMD_HIP(hipFuncSetAttribute((const void*)kern3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-      int dev = 0, cus = 0;
-      CAMD_HIP(hipGetDevice(&dev));
-      CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      const unsigned grid3 = (unsigned)((a.count + WAVES3 - 1) / WAVES3);
-      const unsigned persistent = cus > 0 && grid3 > (unsigned)cus ? (unsigned)cus : grid3;
-      if (persistent < grid3) {
-        if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
-        CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
-      }
-      hipLaunchKernelGGL(kern3, dim3(persistent), dim3(64 * WAVES3), lds3, stream, a);
-      CAMD_HIP(hipGetLastError());
-      return CAMD_OK;
-    }
     if (schedule == 2) {
       auto kern2 = wave_pbs_kernel_v2<T, K, BL>;
       CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1928,7 +1691,7 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
 
 }  // namespace
 
-size_t wave_scratch_bytes() { return (size_t)SYNC_GROUPS * SYNC_STRIDE * sizeof(uint32_t); }
+size_t wave_scratch_bytes() { return 2 * (size_t)SYNC_GROUPS * SYNC_STRIDE * sizeof(uint32_t); }
 
 // the shortint instances (64-bit torus) are the default for their sets; the boolean one is opt-in
 bool wave_default(const camd_params& p) {

@@ -144,9 +144,19 @@ int camd_ks_batch(camd_server_key* key, const void* ct_in, void* ct_out, size_t 
 /* ---- device-pointer batch entry points (asynchronous on `stream`) ----
  * Same semantics; pointers are device memory on the key's GPU. lut_ids is a device pointer or
  * NULL. Scratch is owned by the key and grown on demand (growth synchronises the device);
- * camd_reserve sizes it ahead of time for `count` ciphertexts. Calls on one key must be
- * issued from one thread at a time and on one stream at a time. */
+ * camd_reserve sizes it ahead of time for `count` ciphertexts. Calls on one key are serialised:
+ * a call on another stream than the previous one (the host-pointer entry points use a stream of
+ * the context) first makes its stream wait for the previous call's kernels, because all calls
+ * on a key share its scratch buffers; use one key per stream for concurrent work.
+ * A look-up table id that is out of range cannot be rejected up front here (the ids are in device
+ * memory): the kernel bootstraps that ciphertext with table 0 and raises a flag in a host-visible
+ * status word, and the NEXT call on the key (any batch entry point, or camd_server_key_check)
+ * fails with CAMD_EINVAL and clears the flag. */
 int camd_reserve(camd_server_key* key, size_t count);
+/* Synchronises `stream` and reports whether any device-pointer call on the key since the last
+ * report had a look-up table id out of range (CAMD_EINVAL) - the counterpart, for asynchronous
+ * calls, of the id check the host-pointer entry points make before launching. */
+int camd_server_key_check(camd_server_key* key, void* stream);
 int camd_ks_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,
                              void* ct_out, size_t count, void* stream);
 int camd_pbs_ks_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,

@@ -338,3 +338,45 @@ def test_wave_kernel_small_shortint_sets(gpu_ctx, pname):
     out = dk.ks_pbs(many, np.tile(ids, 1100 // count + 1)[:1027])
     assert np.array_equal(out[:count], got) and np.array_equal(out[1027 - 3:], got[(1027 - 3) % count:(1027 - 3) % count + 3])
     dk.close()
+
+
+@pytest.mark.parametrize("pname,count", [("PARAM_MESSAGE_4_CARRY_4", 16), ("PARAM_MESSAGE_1_CARRY_7", 8)])
+def test_largest_polynomial_full_size_bit_exact(gpu_ctx, pname, count):
+    """The largest-polynomial class (N = 16384, two and three decomposition levels) at its FULL
+    LWE dimension with real keys: keyswitch + bootstrap through the C ABI must give the oracle's
+    ciphertexts word for word (the register-blocked kernel's contract) and every ciphertext must
+    decrypt to f(m) (the property of concrete-shortint/src/server_key/tests.rs:252-277).
+    Parameter sets: concrete-shortint/src/parameters/mod.rs:719-736 and :665-682.
+    The 1 GB bootstrap key is generated by the library's multithreaded host key generation, which
+    is the same algorithm as the oracle's single-threaded one (tests/test_host_cpu.py compares them)."""
+    from concrete_amd import client as CL
+
+    p = P.SHORTINT_BY_NAME[pname]
+    o = O.Oracle(p, 64)
+    rng = CL.Rng(0xBEEF)
+    small = CL.gen_binary_key(rng, 64, p.lwe_dimension)
+    glwe = CL.gen_binary_key(rng, 64, p.glwe_dimension * p.polynomial_size)
+    bsk = CL.gen_bootstrap_key(rng, p, 64, small, glwe, threads=16)
+    ksk = CL.gen_keyswitch_key(rng, p, 64, glwe, small)
+    dk = DeviceServerKey.from_standard_keys(gpu_ctx, p, bsk, ksk, variant=CAMD_PBS_AUTO)
+    assert dk.variant == CAMD_PBS_BLOCK
+    fbsk = o.bsk_to_fourier(bsk)
+    del bsk
+    msg, sup = p.message_modulus, p.message_modulus * p.carry_modulus
+    fs = [lambda x: x % msg, lambda x: x // msg]
+    luts = [o.generate_accumulator(f) for f in fs]
+    for l in luts:
+        dk.upload_lut(l)
+    delta = O.shortint_delta(p)
+    # every message class: both ends of the range, both sides of the padding-bit boundary, carries
+    msgs = ([0, 1, msg - 1, msg, msg + 1, sup // 2 - 1, sup // 2, sup // 2 + 1, sup - 2, sup - 1]
+            + [(37 * i + 5) % sup for i in range(count)])[:count]
+    orng = O.Rng(0xF00D)
+    cts = np.stack([o.lwe_encrypt(orng, glwe, m * delta, p.lwe_modular_std_dev) for m in msgs])
+    ids = (np.arange(count) % 2).astype(np.uint32)
+    got = dk.ks_pbs(cts, ids)
+    want = o.ks_pbs_batch(ksk, fbsk, np.concatenate(luts), ids, cts, threads=16)
+    assert np.array_equal(got, want)
+    for i, m in enumerate(msgs):
+        assert O.shortint_decode(p, o.lwe_phase(glwe, got[i])) == fs[i % 2](m), (i, m)
+    dk.close()

@@ -378,3 +378,79 @@ def test_latency_schedule_gives_the_words_of_the_third_schedule(gpu_ctx, keys_2_
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert np.array_equal(got, np.load(path))
+
+
+def test_device_batch_then_host_batch_without_sync(gpu_ctx):
+    """A device-pointer call returns while its kernels run on the caller's stream; a host-pointer
+    call on the same key right behind it uses the same scratch buffers on the context's stream.
+    The library orders the two: both results must be right, with no synchronisation in between."""
+    import torch
+
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    ks = get_keys(p, 64, n_override=48)
+    o = ks.o
+    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    lut = o.generate_accumulator(lambda x: x % 4)
+    dk.upload_lut(lut)
+    big_n, small_n = 2048, 64   # the device batch is still running when the host batch arrives
+    rs = np.random.RandomState(3)
+    msgs = rs.randint(0, 4, size=big_n)
+    cts = encrypt_batch(ks, msgs[:256])
+    cts = np.concatenate([cts] * (big_n // 256))
+    host_cts = encrypt_batch(ks, (np.arange(small_n) % 4))
+    want_dev = o.ks_pbs_batch(ks.ksk, ks.fbsk, lut, None, cts[:256], threads=8)
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    d_out = torch.zeros_like(d_in)
+    side = torch.cuda.Stream()
+    dk.reserve(big_n)
+    for _ in range(3):
+        d_out.zero_()
+        torch.cuda.synchronize()
+        dk.ks_pbs_device(d_in, None, d_out, big_n, side.cuda_stream)
+        got_host = dk.ks_pbs(host_cts)                       # no synchronisation in between
+        side.synchronize()
+        got_dev = d_out.cpu().numpy().view(np.uint64)
+        for got, ref_cts, count in ((got_dev, cts, big_n), (got_host, host_cts, small_n)):
+            for i in range(0, count, 7):
+                exp = O.shortint_decode(p, o.lwe_phase(ks.glwe, ref_cts[i])) % 4
+                assert O.shortint_decode(p, o.lwe_phase(ks.glwe, got[i])) == exp, i
+        # the copies of the 256 distinct inputs all give the same words, and decrypt like the oracle's
+        assert np.array_equal(got_dev[:256], got_dev[256:512])
+        for i in range(0, 256, 5):
+            assert O.shortint_decode(p, o.lwe_phase(ks.glwe, got_dev[i])) == O.shortint_decode(p, o.lwe_phase(ks.glwe, want_dev[i]))
+    dk.close()
+
+
+@pytest.mark.parametrize("variant", [CAMD_PBS_GENERIC, CAMD_PBS_WAVE])
+def test_device_call_reports_a_bad_lut_id(gpu_ctx, variant):
+    """The host entry points reject a look-up table id that is out of range before launching. A
+    device-pointer call cannot: its kernel flags the launch, and the next call on the key fails
+    with CAMD_EINVAL instead of silently handing back results computed with table 0."""
+    import torch
+
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    ks = get_keys(p, 64, n_override=10)
+    o = ks.o
+    dk = make_device_key(gpu_ctx, ks, variant)
+    dk.upload_lut(o.generate_accumulator(lambda x: x % 4))
+    dk.upload_lut(o.generate_accumulator(lambda x: x // 4))
+    cts = encrypt_batch(ks, [0, 1, 2, 3, 1, 2])
+    with pytest.raises(Exception, match="lut id out of range"):
+        dk.ks_pbs(cts, np.array([0, 1, 2, 0, 0, 0], dtype=np.uint32))
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    d_out = torch.zeros_like(d_in)
+    good = torch.tensor([0, 1, 0, 1, 1, 0], dtype=torch.int32).cuda()
+    bad = torch.tensor([0, 1, 7, 1, 1, 0], dtype=torch.int32).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    dk.ks_pbs_device(d_in, good, d_out, 6, stream)
+    dk.check(stream)                                         # nothing to report
+    dk.ks_pbs_device(d_in, bad, d_out, 6, stream)
+    with pytest.raises(Exception, match="look-up table id out of range"):
+        dk.check(stream)
+    dk.check(stream)                                         # the report clears the flag
+    dk.ks_pbs_device(d_in, bad, d_out, 6, stream)
+    torch.cuda.synchronize()
+    with pytest.raises(Exception, match="look-up table id out of range"):
+        dk.ks_pbs(cts)                                       # any later call on the key reports it
+    assert dk.ks_pbs(cts).shape == cts.shape
+    dk.close()
