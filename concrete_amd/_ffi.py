@@ -59,6 +59,7 @@ SYMBOLS = {
     "camd_reserve": (_i, [_vp, _sz]),
     "camd_server_key_check": (_i, [_vp, _vp]),
     "camd_ks_pbs_batch_device": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "camd_ks_pbs_batch_device_noalloc": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "camd_pbs_ks_batch_device": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "camd_pbs_batch_device": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "camd_ks_batch_device": (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -212,6 +212,10 @@ class DeviceServerKey:
     def ks_pbs_device(self, ct_in, lut_ids, ct_out, count: int, stream: int = 0) -> None:
         self._dev(_ffi.lib().camd_ks_pbs_batch_device, ct_in, lut_ids, ct_out, count, stream)
 
+    def ks_pbs_device_noalloc(self, ct_in, lut_ids, ct_out, count: int, stream: int = 0) -> None:
+        """ks_pbs_device through the entry point that allocates nothing (fixed scratch, bounded batch)."""
+        self._dev(_ffi.lib().camd_ks_pbs_batch_device_noalloc, ct_in, lut_ids, ct_out, count, stream)
+
     def pbs_ks_device(self, ct_in, lut_ids, ct_out, count: int, stream: int = 0) -> None:
         self._dev(_ffi.lib().camd_pbs_ks_batch_device, ct_in, lut_ids, ct_out, count, stream)
 

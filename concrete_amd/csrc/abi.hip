@@ -25,11 +25,23 @@ int fail(int code, const std::string& msg) {
 
 using namespace camd;
 
+// Scratch of the entry point that allocates nothing (camd_ks_pbs_batch_device_noalloc): a
+// file-scope device array, so it exists from the moment the code object is loaded on a GPU and
+// costs no hipMalloc. Every GPU the library runs on holds its own copy, at its own address, until
+// the process ends. Layout: [arrival / member counters of the wave kernels | keyswitch output].
+constexpr size_t NOALLOC_COUNTER_BYTES = 4096;
+constexpr size_t NOALLOC_MID_BYTES = (size_t)16 << 20;
+constexpr size_t NOALLOC_BYTES = NOALLOC_COUNTER_BYTES + NOALLOC_MID_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
 struct camd_context {
   int device = 0;
   hipStream_t stream = nullptr;    // kernels of the host-pointer entry points
   hipStream_t copy_in = nullptr;   // their host -> device copies
   hipStream_t copy_out = nullptr;  // their device -> host copies
+  // address of `scratch` on THIS context's GPU (hipGetSymbolAddress at context creation). Host
+  // code must use this pointer, never the array's name, which is only a host-side stand-in.
+  unsigned char* noalloc_scratch = nullptr;
 };
 
 namespace {
@@ -301,14 +313,16 @@ struct TimedRegion {
 
 template <typename T>
 int run_pbs(camd_server_key* key, const T* in, size_t in_stride, const uint32_t* ids, T* out, size_t out_stride,
-            size_t count, hipStream_t s) {
+            size_t count, hipStream_t s, void* scratch_override = nullptr) {
   if (key->lut_count == 0) return fail(CAMD_EINVAL, "no look-up table uploaded for this key");
   const camd_params& p = key->p;
   PbsLaunch<T> a{};
   a.ct_in = in; a.in_stride = in_stride; a.ct_out = out; a.out_stride = out_stride;
   a.lut_ids = ids; a.luts = (const T*)key->luts.ptr; a.lut_count = key->lut_count; a.count = count;
-  a.fbsk = key->fbsk(); a.tables = key->tables; a.scratch = key->pbs_scratch.ptr; a.status = key->status;
+  a.fbsk = key->fbsk(); a.tables = key->tables; a.status = key->status;
+  a.scratch = scratch_override ? scratch_override : key->pbs_scratch.ptr;
   a.n = p.lwe_dimension; a.k = p.glwe_dimension; a.N = p.polynomial_size; a.level = p.pbs_level; a.base_log = p.pbs_base_log;
+  if (scratch_override) return wave_launch_pbs<T>(a, s);   // the caller checked the family; no events are created here
   TimedRegion t(key, true, s);
   if (key->variant == CAMD_PBS_WAVE) return wave_launch_pbs<T>(a, s);
   if (key->variant == CAMD_PBS_BLOCK) {
@@ -320,8 +334,12 @@ int run_pbs(camd_server_key* key, const T* in, size_t in_stride, const uint32_t*
 }
 
 template <typename T>
-int run_ks(camd_server_key* key, const T* in, size_t in_stride, T* out, size_t out_stride, size_t count, hipStream_t s) {
+int run_ks(camd_server_key* key, const T* in, size_t in_stride, T* out, size_t out_stride, size_t count, hipStream_t s,
+           bool timed = true) {
   const camd_params& p = key->p;
+  if (!timed)
+    return launch_keyswitch<T>(in, in_stride, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
+                               p.ks_base_log, p.ks_level, count, s);
   TimedRegion t(key, false, s);
   return launch_keyswitch<T>(in, in_stride, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
                              p.ks_base_log, p.ks_level, count, s);
@@ -636,6 +654,12 @@ int camd_context_create(int device_id, camd_context** out) {
   camd_context* ctx = new (std::nothrow) camd_context();
   if (!ctx) return fail(CAMD_ENOMEM, "out of host memory");
   ctx->device = device_id;
+  // address of the fixed scratch on this GPU (the device is current: DeviceGuard above)
+  e = hipGetSymbolAddress((void**)&ctx->noalloc_scratch, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !ctx->noalloc_scratch) {
+    delete ctx;
+    return fail(CAMD_EHIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+  }
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking);
@@ -820,6 +844,47 @@ int camd_reserve(camd_server_key* key, size_t count) {
 int camd_ks_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out, size_t count,
                              void* stream) {
   return dispatch_device(key, Op::KsPbs, ct_in, lut_ids, ct_out, count, stream);
+}
+
+int camd_ks_pbs_batch_device_noalloc(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out,
+                                     size_t count, void* stream) {
+  if (!key || (!ct_in && count) || (!ct_out && count)) return fail(CAMD_EINVAL, "null argument");
+  if (key->variant != CAMD_PBS_WAVE)
+    return fail(CAMD_EINVAL, "the no-allocation entry point serves keys of the wave kernel family only (the other "
+                             "families need per-ciphertext scratch that grows with the batch)");
+  const size_t small1 = (size_t)key->p.lwe_dimension + 1, big1 = key->big() + 1;
+  const size_t max_count = NOALLOC_MID_BYTES / (small1 * key->word);
+  if (count > max_count)
+    return fail(CAMD_EINVAL, "batch too large for the no-allocation entry point: its fixed scratch holds the keyswitch "
+                             "output of at most " + std::to_string(max_count) + " ciphertexts of this parameter set, " +
+                             std::to_string(count) + " were given");
+  std::lock_guard<std::mutex> lock(key->mu);
+  int rc = report_status(key);
+  if (rc != CAMD_OK) return rc;
+  if (count == 0) return CAMD_OK;
+  DeviceGuard g(key->ctx->device);
+  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
+  unsigned char* base = key->ctx->noalloc_scratch;   // this GPU's copy of the array
+  if (!base) return fail(CAMD_EHIP, "the fixed scratch of this GPU was not resolved at context creation");
+  hipStream_t s = (hipStream_t)stream;
+  rc = order_after_device_calls(key, s);
+  if (rc != CAMD_OK) return rc;
+  // The array keeps the previous call's contents. The counters are cleared by the launch itself
+  // (hipMemsetAsync on `s`, inside wave_launch_pbs, whenever the kernel will use them); the keyswitch
+  // writes every word of its output rows before the bootstrap reads them.
+  void* counters = base;
+  void* mid = base + NOALLOC_COUNTER_BYTES;
+  if (key->p.torus_bits == 64) {
+    rc = run_ks<uint64_t>(key, (const uint64_t*)ct_in, big1, (uint64_t*)mid, small1, count, s, false);
+    if (rc == CAMD_OK) rc = run_pbs<uint64_t>(key, (const uint64_t*)mid, small1, lut_ids, (uint64_t*)ct_out, big1, count, s, counters);
+  } else {
+    rc = run_ks<uint32_t>(key, (const uint32_t*)ct_in, big1, (uint32_t*)mid, small1, count, s, false);
+    if (rc == CAMD_OK) rc = run_pbs<uint32_t>(key, (const uint32_t*)mid, small1, lut_ids, (uint32_t*)ct_out, big1, count, s, counters);
+  }
+  CAMD_HIP(hipEventRecord(key->device_done, s));
+  key->device_stream = s;
+  key->device_pending = true;
+  return rc;
 }
 int camd_pbs_ks_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out, size_t count,
                              void* stream) {

@@ -159,6 +159,19 @@ int camd_reserve(camd_server_key* key, size_t count);
 int camd_server_key_check(camd_server_key* key, void* stream);
 int camd_ks_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,
                              void* ct_out, size_t count, void* stream);
+/* camd_ks_pbs_batch_device for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference. It
+ * calls no hipMalloc, hipFree or other allocating routine: the keyswitch output and the kernels'
+ * counters live in a fixed 16 MiB + 4 KiB device array that is part of the library's code object
+ * (each GPU holds its own copy for the life of the process). Limits: keys of the wave kernel
+ * family only, and count * (n + 1) * word bytes <= 16 MiB (2723 ciphertexts for
+ * PARAM_MESSAGE_2_CARRY_2); anything beyond fails with CAMD_EINVAL and a message. Results are
+ * those of camd_ks_pbs_batch_device. All calls on one GPU share the array, whichever key or
+ * context they use: calls that overlap in time on one GPU race on it and must be serialised by
+ * the caller (calls on one key are serialised by the library, as above). Kernel timing
+ * (camd_timing_*) does not cover this entry point. */
+int camd_ks_pbs_batch_device_noalloc(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,
+                                     void* ct_out, size_t count, void* stream);
 int camd_pbs_ks_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,
                              void* ct_out, size_t count, void* stream);
 int camd_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,
