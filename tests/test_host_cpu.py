@@ -38,6 +38,33 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.camd_version()
 
 
+def test_rust_declarations_match_the_headers():
+    """rust/concrete-amd-sys/src/lib.rs is generated from the two headers: the committed file must
+    be what the generator writes today, every declared function must be in it exactly once with
+    the header's argument count, and the wrapper crates may only call functions it declares."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gen_rust_sys as G
+
+    text = open(G.OUT).read()
+    assert text == G.render(), "run python scripts/gen_rust_sys.py"
+    decls = G.declarations()
+    assert {d[0] for d in decls} == declared_symbols()
+    for name, _ret, params in decls:
+        m = re.findall(r"pub fn %s\(([^)]*)\)" % name, text)
+        assert len(m) == 1, name
+        assert len([a for a in m[0].split(",") if a.strip()]) == len(params), name
+    # struct layouts: same field order and widths as the C structs
+    assert re.search(r"pub struct CamdParams \{\s*pub lwe_dimension: u32,\s*pub glwe_dimension: u32,\s*pub polynomial_size: u32,"
+                     r"\s*pub pbs_base_log: u32,\s*pub pbs_level: u32,\s*pub ks_base_log: u32,\s*pub ks_level: u32,"
+                     r"\s*pub torus_bits: u32,", text)
+    import ctypes
+
+    assert ctypes.sizeof(_ffi.CamdRng) == 4 * 8 + 8 + 4 + 4 + 8 * 8   # CamdRng in lib.rs: [u64;4], u64, u32, u32, [u64;8]
+    for wrapper in ("rust/concrete-shortint-amd/src/lib.rs", "rust/concrete-boolean-amd/src/amd.rs"):
+        used = set(re.findall(r"\b(camd_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, wrapper)).read()))
+        assert used and used <= {d[0] for d in decls}, used - {d[0] for d in decls}
+
+
 def test_no_gpu_is_an_error_not_a_fallback():
     """Without a usable device the library reports CAMD_ENODEV (or the device is there)."""
     lib = _ffi.lib()
