@@ -110,6 +110,8 @@ struct camd_server_key {
   // scratch
   DeviceBuffer mid;         // keyswitch output (shortint order) or bootstrap output (boolean order)
   DeviceBuffer pbs_scratch;
+  DeviceBuffer ks_limbs;    // keyswitch key as balanced byte limbs (matrix-core keyswitch), derived from the blob
+  DeviceBuffer ks_digits;   // digits of a batch (matrix-core keyswitch)
   DeviceBuffer stage_in, stage_out, stage_ids;
   std::mutex mu;            // guards scratch, look-up tables, timing and the launch order of both kinds of entry point
   Timing timing;
@@ -231,6 +233,8 @@ int key_alloc(camd_context* ctx, const camd_params& p, int variant, camd_server_
   return CAMD_OK;
 }
 
+int key_derive(camd_server_key* key, hipStream_t s);
+
 template <typename T>
 int key_fill(camd_server_key* key, const void* bsk_host, const void* ksk_host) {
   const camd_params& p = key->p;
@@ -252,11 +256,36 @@ int key_fill(camd_server_key* key, const void* bsk_host, const void* ksk_host) {
     e = hipMemcpyAsync((char*)key->blob + key->fbsk_bytes, ksk_host, key->ksk_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) rc = fail(CAMD_EHIP, std::string("ksk upload: ") + hipGetErrorString(e));
+    if (rc == CAMD_OK) rc = key_derive(key, s);
   } else {
     (void)hipStreamSynchronize(s);
   }
   (void)hipFree(d_std);
   return rc;
+}
+
+// Smallest batch that goes to the matrix-core keyswitch; below it the f64-FMA kernel (which splits
+// the key rows of a small batch over the chip) is used. CAMD_KS_MFMA_MIN overrides it (0 = never).
+size_t ks_mfma_min() {
+  const char* e = std::getenv("CAMD_KS_MFMA_MIN");
+  if (!e || !*e) return 128;
+  const long v = std::strtol(e, nullptr, 10);
+  return v <= 0 ? SIZE_MAX : (size_t)v;
+}
+
+// the keyswitch key of the blob, split into balanced byte limbs for the matrix cores
+int key_derive(camd_server_key* key, hipStream_t s) {
+  const camd_params& p = key->p;
+  const uint32_t big = (uint32_t)key->big();
+  if (!keyswitch_mfma_supported(big, p.ks_base_log, p.ks_level)) return CAMD_OK;
+  int rc = key->ks_limbs.ensure(keyswitch_mfma_limb_bytes(big, p.lwe_dimension, p.ks_level, (int)key->word));
+  if (rc != CAMD_OK) return rc;
+  rc = p.torus_bits == 64
+           ? keyswitch_mfma_prepare<uint64_t>((const uint64_t*)key->ksk(), (int8_t*)key->ks_limbs.ptr, big, p.lwe_dimension, p.ks_level, s)
+           : keyswitch_mfma_prepare<uint32_t>((const uint32_t*)key->ksk(), (int8_t*)key->ks_limbs.ptr, big, p.lwe_dimension, p.ks_level, s);
+  if (rc != CAMD_OK) return rc;
+  CAMD_HIP(hipStreamSynchronize(s));
+  return CAMD_OK;
 }
 
 void key_free(camd_server_key* key) {
@@ -269,6 +298,8 @@ void key_free(camd_server_key* key) {
   key->luts.release();
   key->mid.release();
   key->pbs_scratch.release();
+  key->ks_limbs.release();
+  key->ks_digits.release();
   key->stage_in.release();
   key->stage_out.release();
   key->stage_ids.release();
@@ -280,6 +311,10 @@ int reserve_locked(camd_server_key* key, size_t count) {
   const size_t mid_words = std::max<size_t>(key->big() + 1, p.lwe_dimension + 1);
   int rc = key->mid.ensure(count * mid_words * key->word);
   if (rc != CAMD_OK) return rc;
+  if (key->ks_limbs.ptr && count >= ks_mfma_min()) {
+    rc = key->ks_digits.ensure(keyswitch_mfma_digit_bytes((uint32_t)key->big(), p.ks_level, count));
+    if (rc != CAMD_OK) return rc;
+  }
   if (key->variant == CAMD_PBS_GENERIC) {
     unsigned grid = 1;
     const size_t bytes = generic_scratch_bytes(p.glwe_dimension, p.polynomial_size, (int)key->word, &grid, count);
@@ -337,10 +372,14 @@ template <typename T>
 int run_ks(camd_server_key* key, const T* in, size_t in_stride, T* out, size_t out_stride, size_t count, hipStream_t s,
            bool timed = true) {
   const camd_params& p = key->p;
-  if (!timed)
+  if (!timed)   // the entry point that allocates nothing: the kernel that needs no digit scratch
     return launch_keyswitch<T>(in, in_stride, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
                                p.ks_base_log, p.ks_level, count, s);
   TimedRegion t(key, false, s);
+  if (key->ks_limbs.ptr && count >= ks_mfma_min() &&
+      key->ks_digits.bytes >= keyswitch_mfma_digit_bytes((uint32_t)key->big(), p.ks_level, count))
+    return launch_keyswitch_mfma<T>(in, in_stride, out, out_stride, (const int8_t*)key->ks_limbs.ptr, (int8_t*)key->ks_digits.ptr,
+                                    (uint32_t)key->big(), p.lwe_dimension, p.ks_base_log, p.ks_level, count, s);
   return launch_keyswitch<T>(in, in_stride, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
                              p.ks_base_log, p.ks_level, count, s);
 }
@@ -772,6 +811,11 @@ int camd_server_key_import_blob(camd_context* ctx, const camd_params* params, in
   if (e != hipSuccess) {
     key_free(key);
     return fail(CAMD_EHIP, std::string("blob copy: ") + hipGetErrorString(e));
+  }
+  rc = key_derive(key, (hipStream_t)stream);
+  if (rc != CAMD_OK) {
+    key_free(key);
+    return rc;
   }
   *out = key;
   return CAMD_OK;

@@ -46,6 +46,19 @@ int launch_keyswitch(const T* ct_in, size_t in_stride, T* ct_out, size_t out_str
                      uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level, size_t count,
                      hipStream_t stream);
 
+// ---- keyswitch on the matrix cores (keyswitch_mfma.hip): same result, for batches ----
+// limbs: the key split into balanced byte limbs (keyswitch_mfma_prepare, once per key);
+// digits: scratch of keyswitch_mfma_digit_bytes(count) bytes
+bool keyswitch_mfma_supported(uint32_t in_dim, uint32_t base_log, uint32_t level);
+size_t keyswitch_mfma_limb_bytes(uint32_t in_dim, uint32_t out_dim, uint32_t level, int torus_bytes);
+size_t keyswitch_mfma_digit_bytes(uint32_t in_dim, uint32_t level, size_t count);
+template <typename T>
+int keyswitch_mfma_prepare(const T* ksk, int8_t* limbs, uint32_t in_dim, uint32_t out_dim, uint32_t level, hipStream_t stream);
+template <typename T>
+int launch_keyswitch_mfma(const T* ct_in, size_t in_stride, T* ct_out, size_t out_stride, const int8_t* limbs,
+                          int8_t* digits, uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level, size_t count,
+                          hipStream_t stream);
+
 // ---- leveled operations on device ciphertexts (linear.hip) ----
 template <typename T>
 int launch_lwe_axpby(T* out, size_t out_stride, const T* x, size_t x_stride, T alpha, const T* y, size_t y_stride, T beta,

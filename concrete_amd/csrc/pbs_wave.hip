@@ -978,14 +978,14 @@ constexpr size_t lat_slab_bytes() {
 // ---- the bootstrap, latency schedule: k+1 waves per ciphertext ----
 // A batch smaller than the chip leaves most SIMDs idle while each lone wave walks its n CMUXes
 // at one instruction per four cycles. Here the k+1 waves of a workgroup share one ciphertext:
-// wave c owns polynomial c of the accumulator (in registers, as in the third schedule), rotates,
+// wave c owns polynomial c of the accumulator (in registers), rotates,
 // decomposes and forward-transforms it, and publishes the spectrum in LDS; after one barrier it
 // multiplies all k+1 spectra with column c of the key row (requested at the top of the
 // iteration, so the loads fly behind the forward transform), transforms back and adds into its
 // polynomial. One transform each way per wave and CMUX instead of k+1. The spectra alternate
 // between two images, so one barrier per CMUX is enough: a wave can only overwrite an image after
 // the barrier of the following CMUX, which every reader of that image has reached by then.
-// Same products in the same order as the third schedule, hence the same ciphertext words.
+// Same products in the same order as the first one-wave schedule, hence the same ciphertext words.
 template <typename T, int K, int L>
 constexpr size_t wavelat_lds_bytes() {
   return TAB_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T, K>() + 2 * (size_t)(K + 1) * L * 512 * sizeof(double2);
@@ -1108,206 +1108,6 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
     } else if (lane == 0) {
       out[K * N] = acc[0];
     }
-  }
-}
-
-// ---- the bootstrap, throughput schedule: k+1 waves per ciphertext, three waves per SIMD ----
-// The second schedule runs one wave per SIMD (its LDS accumulator and the parked key rows leave no
-// room for a second one), and a lone wave issues one instruction per four cycles whatever the
-// instruction is: more than half of its issue slots go to integer, LDS and register-move
-// instructions that would cost two cycles, or none of the vector ALU's time, beside another wave.
-// Here a ciphertext is spread over k+1 waves as in the latency schedule (wave c owns polynomial c:
-// accumulator in registers, one transform each way per CMUX, column c of the key row), but sized
-// so that a CU holds four ciphertexts = twelve waves, three per SIMD:
-//   * one 9 KiB LDS image per wave serves, in turn, as staging row of the rotation, exchange image
-//     of the forward transform, published spectrum (read by the sibling waves), and exchange image
-//     of the inverse transform. Two barriers per CMUX among the k+1 waves of a ciphertext order
-//     these uses: one after the spectra are published, one after every wave has multiplied them
-//     with its key column. They are counters in LDS, not s_barrier: the ciphertexts of a workgroup
-//     run independently of one another, so that their LDS-heavy and ALU-heavy phases interleave
-//     on the CU instead of all twelve waves reaching each phase together.
-//   * at most 168 registers per wave: the key column (24 x 16 bytes per lane) is requested in two
-//     halves, the second after the forward transform has freed its registers.
-// A workgroup is TRIO_CTS ciphertexts (so that the twiddle tables are staged once for several).
-constexpr int TRIO_CTS = 1;
-constexpr size_t TRIO_IMAGE = 2 * PLANE * sizeof(double);   // 9216 bytes
-template <int K>
-constexpr size_t trio_lds_bytes() {
-  return TAB_COUNT * sizeof(double2) + (size_t)TRIO_CTS * (K + 1) * TRIO_IMAGE + 64 * sizeof(uint32_t);
-}
-
-// Barrier among the waves that share one ciphertext: a monotonic arrival counter in LDS. A wave's
-// LDS operations execute in order, so its earlier LDS writes are in place before its arrival is.
-__device__ __forceinline__ void group_barrier(uint32_t* counter, uint32_t target, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-    __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <typename T, int K, int BL>
-__global__ __launch_bounds__(64 * (K + 1) * TRIO_CTS) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void wave_pbs_kernel_trio(PbsLaunch<T> a) {
-  constexpr int N = 1024, M = 512, LOGN = 10, R = K + 1, NS = R * R, WG_WAVES = R * TRIO_CTS;
-  static_assert(N * sizeof(T) <= TRIO_IMAGE, "staging row does not fit the image");
-  extern __shared__ __align__(16) char smem[];
-  double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * WG_WAVES) tab[t] = a.tables[t];
-  uint32_t* counters = (uint32_t*)(smem + TAB_COUNT * sizeof(double2) + (size_t)WG_WAVES * TRIO_IMAGE);
-  if (threadIdx.x < 64) counters[threadIdx.x] = 0u;
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = wid / R;           // ciphertext of the workgroup
-  const int c = wid - grp * R;       // the polynomial (and key column) this wave owns
-  char* images = smem + TAB_COUNT * sizeof(double2);
-  double* sre = (double*)(images + (size_t)wid * TRIO_IMAGE);
-  double* sim = sre + PLANE;
-  T* stage = (T*)sre;
-  double2* own_spec = (double2*)sre;
-  const double2* grp_spec = (const double2*)(images + (size_t)grp * R * TRIO_IMAGE);
-  constexpr int SPEC_STRIDE = (int)(TRIO_IMAGE / sizeof(double2));
-  const uint32_t n = a.n;
-  uint32_t* arrivals = counters + grp * 16;   // one counter per ciphertext of the workgroup, 64 bytes apart
-  uint32_t arrived = 0;                        // arrivals this wave has waited for so far
-
-  XcdRendezvous rendezvous;
-  if (a.scratch) rendezvous.enrol(a.scratch, lane);
-  const size_t per_round = (size_t)gridDim.x * TRIO_CTS;
-  uint32_t round = 0;
-  for (size_t first = (size_t)blockIdx.x * TRIO_CTS; first < a.count; first += per_round, round++) {
-    const bool active = first + grp < a.count;
-    const size_t ct = active ? first + grp : a.count - 1;
-    const T* in = a.ct_in + ct * a.in_stride;
-    const uint32_t lut_id = checked_lut_id(a, ct);
-    const T* lut = a.luts + (size_t)lut_id * (R * N) + (size_t)c * N;
-
-    // acc[2q] = coefficient 64q + lane, acc[2q+1] = coefficient 64q + lane + N/2 of the own polynomial
-    T acc[16];
-    {
-      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
-      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        acc[2 * q] = rotated_coeff<T>(lut, 64 * q + lane, d0, N);
-        acc[2 * q + 1] = rotated_coeff<T>(lut, 64 * q + lane + M, d0, N);
-      }
-    }
-
-#ifdef CAMD_PROFILE
-    uint64_t tG = 0, tF = 0, tB1 = 0, tM = 0, tB2 = 0, tI = 0, tR = 0, t0, t1;
-#define TSTAMP(acc) t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1;
-#else
-#define TSTAMP(acc)
-#endif
-    T a_next = wave_uniform(in[0]);
-    for (uint32_t i = 0; i < n; i++) {
-#ifdef CAMD_PROFILE
-      t0 = __builtin_amdgcn_s_memtime();
-#endif
-      const T a_cur = a_next;
-      a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
-      if (a_cur == 0 || !active) continue;   // the reference skips a zero mask element; all k+1 waves see the same value
-      const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
-      // opaque copy of the lane index: LDS, table and key addresses are recomputed in every
-      // iteration (an add each) instead of being hoisted out of the loop, where they would not
-      // fit the 168 registers and be spilled to scratch memory
-      int lane_i = lane;
-      asm volatile("" : "+v"(lane_i));
-#define lane lane_i
-
-      // column c of key row i: slab (row r, column c) at ((r R + c) M), register g at + 64 g
-      const double2* key = a.fbsk + (size_t)i * NS * M + (size_t)c * M + lane;
-      constexpr int EARLY = 12;   // 16-byte requests issued ahead of the forward transform
-      double2 kk[R][8];
-#pragma unroll
-      for (int t = 0; t < EARLY; t++) kk[t >> 3][t & 7] = key[(size_t)((t >> 3) * R) * M + (t & 7) * 64];
-      __builtin_amdgcn_sched_barrier(0);
-
-      // rotation by X^a_hat through the image, digits of (rotated - own), twist
-      double2 x[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        stage[64 * q + lane] = acc[2 * q];
-        stage[64 * q + lane + M] = acc[2 * q + 1];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-        const T v0 = stage[(j0 - a_hat) & (N - 1)], v1 = stage[(j1 - a_hat) & (N - 1)];
-        const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - v0) : v0;
-        const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - v1) : v1;
-        const int32_t d0 = digit_single32<T, BL>((T)(r0 - acc[2 * q]));
-        const int32_t d1 = digit_single32<T, BL>((T)(r1 - acc[2 * q + 1]));
-        x[q] = cmul(make_double2((double)d0, (double)d1), tab[TAB_TWIST + 64 * q + lane]);
-      }
-      TSTAMP(tG)
-      fft512_forward(x, lane, tab, sre, sim);
-#pragma unroll
-      for (int g = 0; g < 8; g++) own_spec[g * 64 + lane] = x[g];
-      TSTAMP(tF)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = EARLY; t < R * 8; t++) kk[t >> 3][t & 7] = key[(size_t)((t >> 3) * R) * M + (t & 7) * 64];
-      if constexpr (TRIO_CTS == 1) {
-        __syncthreads();
-      } else {
-        arrived += R;
-        group_barrier(arrivals, arrived, lane);
-      }
-      TSTAMP(tB1)
-
-      // own column of the external product: sum over the rows of key[r][c] * spectrum r
-#pragma unroll
-      for (int g = 0; g < 8; g++) {
-        double2 v = cmul(kk[0][g], grp_spec[g * 64 + lane]);
-#pragma unroll
-        for (int r = 1; r < R; r++) v = cfma(kk[r][g], grp_spec[r * SPEC_STRIDE + g * 64 + lane], v);
-        x[g] = v;
-      }
-      TSTAMP(tM)
-      if constexpr (TRIO_CTS == 1) {
-        __syncthreads();
-      } else {
-        arrived += R;
-        group_barrier(arrivals, arrived, lane);
-      }
-      TSTAMP(tB2)
-      fft512_inverse(x, lane, tab, sre, sim);
-      TSTAMP(tI)
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const double2 v = cmul_conj(x[q], tab[TAB_TWIST + 64 * q + lane]);
-        acc[2 * q] = torus_accumulate(acc[2 * q], v.x);
-        acc[2 * q + 1] = torus_accumulate(acc[2 * q + 1], v.y);
-      }
-      TSTAMP(tR)
-#undef lane
-    }
-#ifdef CAMD_PROFILE
-    if ((ct == 0 || ct == 5001 || ct == 9002) && lane == 0)
-      printf("ct %lu wave %d cycles per CMUX: gather %lu fwd %lu barrier1 %lu mac %lu barrier2 %lu inv %lu round %lu\n",
-             (unsigned long)ct, c, (unsigned long)(tG / n), (unsigned long)(tF / n), (unsigned long)(tB1 / n),
-             (unsigned long)(tM / n), (unsigned long)(tB2 / n), (unsigned long)(tI / n), (unsigned long)(tR / n));
-#endif
-
-    // sample extraction of coefficient 0: out[c N + (N - j) mod N] = (j == 0) ? p[j] : -p[j]
-    if (active) {
-      T* out = a.ct_out + ct * a.out_stride;
-      if (c < K) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-          out[(size_t)c * N + ((N - j0) & (N - 1))] = (j0 == 0) ? acc[2 * q] : (T)(T(0) - acc[2 * q]);
-          out[(size_t)c * N + (N - j1)] = (T)(T(0) - acc[2 * q + 1]);
-        }
-      } else if (lane == 0) {
-        out[K * N] = acc[0];
-      }
-    }
-    if (first + per_round < a.count) rendezvous.arrive_and_wait(round, lane);
   }
 }
 
@@ -1866,25 +1666,6 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     }
   }
   if constexpr (L == 1) {
-    if (schedule == 4) {
-      constexpr size_t ldst = trio_lds_bytes<K>();
-      static_assert(ldst <= 160 * 1024, "LDS budget exceeded");
-      auto kernt = wave_pbs_kernel_trio<T, K, BL>;
-      CAMD_HIP(hipFuncSetAttribute((const void*)kernt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
-      int dev = 0, cus = 0;
-      CAMD_HIP(hipGetDevice(&dev));
-      CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      const unsigned gridt = (unsigned)((a.count + TRIO_CTS - 1) / TRIO_CTS);
-      const unsigned resident = (unsigned)(cus > 0 ? cus : 1) * (unsigned)((160 * 1024) / ldst);
-      const unsigned persistent = gridt > resident ? resident : gridt;
-      if (persistent < gridt) {
-        if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
-        CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
-      }
-      hipLaunchKernelGGL(kernt, dim3(persistent), dim3(64 * (K + 1) * TRIO_CTS), ldst, stream, a);
-      CAMD_HIP(hipGetLastError());
-      return CAMD_OK;
-    }
     if (schedule == 2) {
       auto kern2 = wave_pbs_kernel_v2<T, K, BL>;
       CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

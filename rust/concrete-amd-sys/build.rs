@@ -4,9 +4,10 @@ use std::env;
 use std::path::PathBuf;
 use std::process::Command;
 
-const SOURCES: [&str; 7] = [
+const SOURCES: [&str; 8] = [
     "abi.hip",
     "keyswitch.hip",
+    "keyswitch_mfma.hip",
     "linear.hip",
     "pbs_generic.hip",
     "pbs_block.hip",

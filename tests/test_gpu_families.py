@@ -380,3 +380,30 @@ def test_largest_polynomial_full_size_bit_exact(gpu_ctx, pname, count):
     for i, m in enumerate(msgs):
         assert O.shortint_decode(p, o.lwe_phase(glwe, got[i])) == fs[i % 2](m), (i, m)
     dk.close()
+
+
+@pytest.mark.parametrize("pname,bits", [("PARAM_MESSAGE_1_CARRY_1", 64), ("PARAM_MESSAGE_4_CARRY_4", 64),
+                                        ("PARAM_MESSAGE_1_CARRY_7", 64), ("DEFAULT_PARAMETERS", 32), ("TFHE_LIB_PARAMETERS", 32)])
+def test_matrix_core_keyswitch_every_torus_and_decomposition(gpu_ctx, pname, bits, monkeypatch):
+    """The integer-MFMA keyswitch over both torus widths and the extremes of the keyswitch
+    decompositions (base 2^2 with 8 levels ... base 2^4 with 5; input dimensions 1024 ... 16384):
+    word for word the oracle's keyswitch and the f64-FMA kernel's."""
+    monkeypatch.setenv("CAMD_KS_MFMA_MIN", "1")
+    p = P.SHORTINT_BY_NAME[pname] if bits == 64 else getattr(P, pname)
+    ks = get_keys(p, bits, n_override=40)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_GENERIC)
+    dt = np.uint64 if bits == 64 else np.uint32
+    rs = np.random.RandomState(9)
+    count = 70
+    cts = (rs.randint(0, 2 ** 31, size=(count, o.big + 1), dtype=np.int64).astype(dt) * dt(2 ** (bits - 31))
+           + rs.randint(0, 2 ** 31, size=(count, o.big + 1), dtype=np.int64).astype(dt))
+    cts[1, :] = dt(2 ** bits - 1)
+    cts[2, :-1] = 0
+    got = dk.ks(cts)
+    assert got.dtype == dt
+    for i in range(0, count, 3):
+        assert np.array_equal(got[i], o.keyswitch(ks.ksk, cts[i])), i
+    monkeypatch.setenv("CAMD_KS_MFMA_MIN", "0")
+    assert np.array_equal(dk.ks(cts), got)
+    dk.close()

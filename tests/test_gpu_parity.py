@@ -321,10 +321,10 @@ def test_concurrent_single_ciphertext_callers_share_launches(gpu_ctx, keys_2_2):
 
 def test_other_wave_schedules_in_their_own_process():
     """The schedule of the wave family is chosen once per process (CAMD_WAVE_SCHEDULE); the first
-    (one row at a time) and third (two waves per SIMD) schedules are kept as selectable variants and
-    must meet the same parity bar as the default. Batches smaller than the chip normally go to the
-    latency schedule (k+1 waves per ciphertext); CAMD_WAVE_LATENCY=0 sends them to the selected
-    schedule, so the small cases are run that way for all three."""
+    (one row at a time, also the instance of the TFHE-lib boolean set) is kept as a selectable variant
+    and must meet the same parity bar as the default. Batches smaller than the chip normally go to
+    the latency schedule (k+1 waves per ciphertext); CAMD_WAVE_LATENCY=0 sends them to the selected
+    schedule, so the small cases are run that way for both."""
     import os
     import subprocess
     import sys
@@ -332,7 +332,7 @@ def test_other_wave_schedules_in_their_own_process():
     if os.environ.get("CAMD_WAVE_SCHEDULE") or os.environ.get("CAMD_WAVE_LATENCY"):
         pytest.skip("already running under a non-default schedule")
     here = os.path.abspath(__file__)
-    for schedule in ("1", "2", "3"):
+    for schedule in ("1", "2"):
         env = dict(os.environ, CAMD_WAVE_SCHEDULE=schedule, CAMD_WAVE_LATENCY="0")
         res = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
                               "ks_pbs_parity_2_2 or trivial_bootstrap or persistent_rounds", "-p", "no:cacheprovider"],
@@ -360,10 +360,10 @@ def test_dump_for_schedule_comparison(gpu_ctx, keys_2_2):
     np.save(path, _schedule_probe(gpu_ctx, keys_2_2))
 
 
-def test_latency_schedule_gives_the_words_of_the_third_schedule(gpu_ctx, keys_2_2, tmp_path):
-    """k+1 waves per ciphertext perform the products and transforms of the third schedule in the
-    same order, so a small batch (latency schedule) and the same batch under CAMD_WAVE_SCHEDULE=3
-    agree word for word."""
+def test_latency_schedule_gives_the_words_of_the_first_schedule(gpu_ctx, keys_2_2, tmp_path):
+    """k+1 waves per ciphertext perform the products and transforms of the first one-wave schedule
+    in the same order (rows outermost, one transform at a time), so a small batch (latency
+    schedule) and the same batch under CAMD_WAVE_SCHEDULE=1 agree word for word."""
     import os
     import subprocess
     import sys
@@ -372,8 +372,8 @@ def test_latency_schedule_gives_the_words_of_the_third_schedule(gpu_ctx, keys_2_
         pytest.skip("already running under a non-default schedule")
     here = os.path.abspath(__file__)
     got = _schedule_probe(gpu_ctx, keys_2_2)
-    path = str(tmp_path / "third.npy")
-    env = dict(os.environ, CAMD_WAVE_SCHEDULE="3", CAMD_WAVE_LATENCY="0", CAMD_DUMP=path)
+    path = str(tmp_path / "first.npy")
+    env = dict(os.environ, CAMD_WAVE_SCHEDULE="1", CAMD_WAVE_LATENCY="0", CAMD_DUMP=path)
     res = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "dump_for_schedule_comparison",
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
@@ -453,4 +453,28 @@ def test_device_call_reports_a_bad_lut_id(gpu_ctx, variant):
     with pytest.raises(Exception, match="look-up table id out of range"):
         dk.ks_pbs(cts)                                       # any later call on the key reports it
     assert dk.ks_pbs(cts).shape == cts.shape
+    dk.close()
+
+
+@pytest.mark.parametrize("count", [1, 37, 300, 1024])
+def test_keyswitch_on_the_matrix_cores_is_bit_exact_2_2(gpu_ctx, keys_2_2, count, monkeypatch):
+    """Batches go to the integer-MFMA keyswitch (balanced byte limbs of the key, i32 accumulation,
+    limbs recombined with shifts): the same words as the oracle, for a lone ciphertext (key rows
+    split over workgroups, atomics), a ragged tile and several tiles."""
+    monkeypatch.setenv("CAMD_KS_MFMA_MIN", "1")
+    ks = keys_2_2
+    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    rs = np.random.RandomState(count)
+    cts = rs.randint(0, 2 ** 63, size=(count, ks.o.big + 1), dtype=np.uint64) * np.uint64(2) + rs.randint(0, 2, size=(count, ks.o.big + 1)).astype(np.uint64)
+    cts[0, :] = np.uint64(2 ** 64 - 1)   # every mask element rounds up and wraps
+    if count > 4:
+        cts[3, :] = 0
+        cts[4, :-1] = 0
+    got = dk.ks(cts)
+    check = range(count) if count <= 64 else list(range(0, count, 17)) + [255, 256, count - 1]
+    for i in check:
+        assert np.array_equal(got[i], ks.o.keyswitch(ks.ksk, cts[i])), i
+    # and the two keyswitch kernels agree on the whole batch
+    monkeypatch.setenv("CAMD_KS_MFMA_MIN", "0")
+    assert np.array_equal(dk.ks(cts), got)
     dk.close()
