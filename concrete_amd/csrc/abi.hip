@@ -264,13 +264,20 @@ int key_fill(camd_server_key* key, const void* bsk_host, const void* ksk_host) {
   return rc;
 }
 
-// Smallest batch that goes to the matrix-core keyswitch; below it the f64-FMA kernel (which splits
-// the key rows of a small batch over the chip) is used. CAMD_KS_MFMA_MIN overrides it (0 = never).
-size_t ks_mfma_min() {
+// Which keyswitch kernel serves a batch. The matrix-core form is faster for every batch size
+// measured (2_2: 0.036 against 0.073 ms for one ciphertext, 0.91 against 6.2 ms for 2^14) except
+// the smallest batches of the N = 16384 sets, whose 98304 key rows the f64-FMA kernel spreads over
+// the chip slightly better (0.24 against 0.30 ms below 32 ciphertexts). CAMD_KS_MFMA_MIN overrides
+// the smallest batch that takes the matrix cores (0 = never).
+bool ks_use_mfma(const camd_server_key* key, size_t count) {
+  if (!key->ks_limbs.ptr) return false;
   const char* e = std::getenv("CAMD_KS_MFMA_MIN");
-  if (!e || !*e) return 128;
-  const long v = std::strtol(e, nullptr, 10);
-  return v <= 0 ? SIZE_MAX : (size_t)v;
+  if (e && *e) {
+    const long v = std::strtol(e, nullptr, 10);
+    return v > 0 && count >= (size_t)v;
+  }
+  const size_t rows = key->big() * key->p.ks_level;
+  return rows <= 32768 || count >= 32;
 }
 
 // the keyswitch key of the blob, split into balanced byte limbs for the matrix cores
@@ -311,7 +318,7 @@ int reserve_locked(camd_server_key* key, size_t count) {
   const size_t mid_words = std::max<size_t>(key->big() + 1, p.lwe_dimension + 1);
   int rc = key->mid.ensure(count * mid_words * key->word);
   if (rc != CAMD_OK) return rc;
-  if (key->ks_limbs.ptr && count >= ks_mfma_min()) {
+  if (ks_use_mfma(key, count)) {
     rc = key->ks_digits.ensure(keyswitch_mfma_digit_bytes((uint32_t)key->big(), p.ks_level, count));
     if (rc != CAMD_OK) return rc;
   }
@@ -376,8 +383,7 @@ int run_ks(camd_server_key* key, const T* in, size_t in_stride, T* out, size_t o
     return launch_keyswitch<T>(in, in_stride, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
                                p.ks_base_log, p.ks_level, count, s);
   TimedRegion t(key, false, s);
-  if (key->ks_limbs.ptr && count >= ks_mfma_min() &&
-      key->ks_digits.bytes >= keyswitch_mfma_digit_bytes((uint32_t)key->big(), p.ks_level, count))
+  if (ks_use_mfma(key, count) && key->ks_digits.bytes >= keyswitch_mfma_digit_bytes((uint32_t)key->big(), p.ks_level, count))
     return launch_keyswitch_mfma<T>(in, in_stride, out, out_stride, (const int8_t*)key->ks_limbs.ptr, (int8_t*)key->ks_digits.ptr,
                                     (uint32_t)key->big(), p.lwe_dimension, p.ks_base_log, p.ks_level, count, s);
   return launch_keyswitch<T>(in, in_stride, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
