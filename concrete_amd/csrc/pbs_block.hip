@@ -36,6 +36,25 @@ namespace camd {
 
 namespace {
 
+// Configuration of the N >= 8192 instances: points per thread (log2), Fourier-sum columns kept in
+// registers, waves per SIMD they are compiled for. Measured on MESSAGE_4_CARRY_4 (N = 16384, 1024
+// ciphertexts), (PL, columns, waves):
+//   (4, 1, 2)  504 ms   512 threads of 16 points; the second column round-trips the global slab
+//                       (1 MB per CMUX and CU) and the compiler spills 123 registers
+//   (4, 2, 2)  439 ms   both columns in registers, 11 spilled
+//   (3, 2, 4)  405 ms   1024 threads of 8 points: one more exchange per transform, but sixteen waves
+//                       per CU to hide the latency of the slab and key accesses
+// MESSAGE_3_CARRY_4 (N = 8192): 201 / 184 / 153 ms; MESSAGE_1_CARRY_7 (three levels): 338 / 300 / 275 ms.
+#ifndef BLOCK_BIG_PL
+#define BLOCK_BIG_PL 3
+#endif
+#ifndef BLOCK_BIG_CREG
+#define BLOCK_BIG_CREG 2
+#endif
+#ifndef BLOCK_BIG_WAVES
+#define BLOCK_BIG_WAVES 4
+#endif
+
 constexpr uint32_t SWZ_BITS = 4;  // a 16-lane group of ds_read_b128 must touch 16 distinct 16-byte units
 
 // Global accesses as (wave-uniform base, 32-bit byte offset): the hardware adds the scalar base
@@ -166,9 +185,10 @@ __device__ __forceinline__ void exchange(double2 (&x)[1 << PL], double2* buf, ui
 
 // waves per SIMD an instance is compiled for: the Fourier sums ((k+1) P complex) and one polynomial
 // slice (P complex) stay in registers, plus about 40 registers of addresses and temporaries
-constexpr int block_waves(int PL, int KP1) {
+constexpr int block_waves(int PL, int KP1, int B = 0) {
   const int need = KP1 * (1 << PL) * 4 + (1 << PL) * 4 + 40;
   const int w = 512 / need;
+  if (B >= 12) return BLOCK_BIG_WAVES;
   if (PL >= 3) return 2;  // room to keep a whole phase's loads in flight beats a third wave per SIMD
   return w > 4 ? 4 : (w < 1 ? 1 : w);
 }
@@ -257,11 +277,11 @@ __global__ __launch_bounds__(1 << (B - PL)) void block_bsk_fourier_kernel(const 
 
 // number of Fourier-sum columns kept in registers; the others live in the workgroup's global
 // slab (N >= 8192: two columns of 16 points do not fit 256 registers next to the transform)
-constexpr int block_reg_columns(int B, int KP1) { return B >= 12 ? 1 : KP1; }
+constexpr int block_reg_columns(int B, int KP1) { return B >= 12 ? BLOCK_BIG_CREG : KP1; }
 
 template <typename T, int B, int PL, int KP1, int LV>
 __global__ __launch_bounds__(1 << (B - PL))
-__attribute__((amdgpu_waves_per_eu(block_waves(PL, block_reg_columns(B, KP1)))))
+__attribute__((amdgpu_waves_per_eu(block_waves(PL, block_reg_columns(B, KP1), B), block_waves(PL, block_reg_columns(B, KP1), B))))
 void block_pbs_kernel(PbsLaunch<T> a) {
   using S = typename Torus<T>::Signed;
   constexpr int P = 1 << PL;
@@ -280,7 +300,8 @@ void block_pbs_kernel(PbsLaunch<T> a) {
   // points per load group of each phase: what fits the registers left next to the Fourier sums
   // and the polynomial slice (a point costs 12 registers in the gather, 6 when the parked states
   // are read back, 4 or 8 in the multiply-accumulate, 8 in the update)
-  constexpr int FREE = 512 / block_waves(PL, CREG) - (CREG * P * 4 + P * 4) - (PL >= 4 ? 64 : 40);
+  constexpr int FREE0 = 512 / block_waves(PL, CREG, B) - (CREG * P * 4 + P * 4) - (PL >= 4 ? 64 : 40);
+  constexpr int FREE = FREE0 < 12 ? 12 : FREE0;
   constexpr int GG = group_points(FREE / 12, P);
   constexpr int GS = group_points(FREE / 6, P);
   constexpr int GM = group_points(FREE / (KP1 > CREG ? 8 : 4), P);
@@ -541,7 +562,7 @@ void block_pbs_kernel(PbsLaunch<T> a) {
   }
 }
 
-int block_pl(uint32_t N) { return N >= 8192 ? 4 : (N >= 1024 ? 3 : (N == 512 ? 2 : 1)); }
+int block_pl(uint32_t N) { return N >= 8192 ? BLOCK_BIG_PL : (N >= 1024 ? 3 : (N == 512 ? 2 : 1)); }
 
 size_t block_lds_bytes(uint32_t N, uint32_t kp1, int torus_bytes, uint32_t level) {
   const uint32_t M = N / 2;
@@ -610,7 +631,7 @@ size_t block_scratch_bytes(const camd_params& p, unsigned* grid_out, size_t coun
   const size_t slab = (size_t)kp1 * N * (p.torus_bits / 8) + (p.pbs_level > 1 ? (size_t)kp1 * N * sizeof(uint32_t) : 0) +
                       (size_t)(kp1 - creg) * (N / 2) * sizeof(double2);
   const size_t threads = (N / 2) >> block_pl(N);
-  size_t per_cu = (size_t)block_waves(block_pl(N), creg) * 256 / threads;  // register budget of the instance
+  size_t per_cu = (size_t)block_waves(block_pl(N), creg, Bits) * 256 / threads;  // register budget of the instance
   const size_t by_lds = (160 * 1024) / block_lds_bytes(N, kp1, (int)(p.torus_bits / 8), p.pbs_level);
   if (per_cu > by_lds) per_cu = by_lds;
   if (per_cu < 1) per_cu = 1;
@@ -630,8 +651,8 @@ int block_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables,
     case 1024: return block_fourier_instance<T, 9, 3>(bsk_std, fbsk, tables, polys, stream);
     case 2048: return block_fourier_instance<T, 10, 3>(bsk_std, fbsk, tables, polys, stream);
     case 4096: return block_fourier_instance<T, 11, 3>(bsk_std, fbsk, tables, polys, stream);
-    case 8192: return block_fourier_instance<T, 12, 4>(bsk_std, fbsk, tables, polys, stream);
-    case 16384: return block_fourier_instance<T, 13, 4>(bsk_std, fbsk, tables, polys, stream);
+    case 8192: return block_fourier_instance<T, 12, BLOCK_BIG_PL>(bsk_std, fbsk, tables, polys, stream);
+    case 16384: return block_fourier_instance<T, 13, BLOCK_BIG_PL>(bsk_std, fbsk, tables, polys, stream);
   }
   return fail(CAMD_EINVAL, "the register-blocked kernel has no instance for this polynomial size");
 }
@@ -647,8 +668,8 @@ int block_launch_pbs(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream) {
     if (N == 1024 && kp1 == 3) return block_launch_instance<T, 9, 3, 3, 1>(a, grid, stream);
     if (N == 2048 && kp1 == 2) return block_launch_instance<T, 10, 3, 2, 1>(a, grid, stream);
     if (N == 4096 && kp1 == 2) return block_launch_instance<T, 11, 3, 2, 3>(a, grid, stream);
-    if (N == 8192 && kp1 == 2) return block_launch_instance<T, 12, 4, 2, 3>(a, grid, stream);
-    if (N == 16384 && kp1 == 2) return block_launch_instance<T, 13, 4, 2, 6>(a, grid, stream);
+    if (N == 8192 && kp1 == 2) return block_launch_instance<T, 12, BLOCK_BIG_PL, 2, 3>(a, grid, stream);
+    if (N == 16384 && kp1 == 2) return block_launch_instance<T, 13, BLOCK_BIG_PL, 2, 6>(a, grid, stream);
   } else {
     if (N == 512 && kp1 == 3) return block_launch_instance<T, 8, 2, 3, 2>(a, grid, stream);
     if (N == 1024 && kp1 == 2) return block_launch_instance<T, 9, 3, 2, 4>(a, grid, stream);

@@ -168,14 +168,14 @@ __device__ __forceinline__ uint64_t add_halves(uint64_t acc, uint32_t hi, uint32
   return ((uint64_t)rhi << 32) | rlo;
 }
 
-// f64 (torus units) -> torus word by magic-constant additions: adding 1.5*2^20 leaves
-// round(fr*2^32) in the low dword of the sum; the remainder, added to 1.5*2^-12, leaves
-// round(rem*2^64) in its mantissa. Round-to-nearest-even; +1/2 and -1/2 give the same word.
+// f64 (torus units) -> torus word by magic-constant additions: with fr = t mod 1 in [0, 1), adding
+// 1.5*2^20 leaves round(fr*2^32) in the low dword of the sum (a carry out of it is a whole turn of
+// the torus); the remainder, added to 1.5*2^-12, leaves round(rem*2^64) in its mantissa.
 template <typename T>
 __device__ __forceinline__ T from_torus_fast(double t);
 template <>
 __device__ __forceinline__ uint64_t from_torus_fast<uint64_t>(double t) {
-  const double fr = t - rint(t);
+  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
   const double a = fr + 0x1.8p20;
   const uint32_t q = (uint32_t)__double2loint(a);
   const double rem = fr - (a - 0x1.8p20);
@@ -186,7 +186,7 @@ __device__ __forceinline__ uint64_t from_torus_fast<uint64_t>(double t) {
 }
 // acc += from_torus_fast(t), without assembling the 64-bit word first
 __device__ __forceinline__ uint64_t torus_accumulate(uint64_t acc, double t) {
-  const double fr = t - rint(t);
+  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
   const double a = fr + 0x1.8p20;
   const uint32_t q = (uint32_t)__double2loint(a);
   const double rem = fr - (a - 0x1.8p20);
@@ -204,7 +204,7 @@ struct TorusSum {
   bool carry;
 };
 __device__ __forceinline__ TorusSum torus_accumulate_low(uint64_t acc, double t) {
-  const double fr = t - rint(t);
+  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
   const double a = fr + 0x1.8p20;
   const uint32_t q = (uint32_t)__double2loint(a);
   const double rem = fr - (a - 0x1.8p20);
@@ -219,12 +219,12 @@ __device__ __forceinline__ uint64_t torus_accumulate_high(const TorusSum& s) {
   return ((uint64_t)hi << 32) | s.lo;
 }
 __device__ __forceinline__ uint32_t torus_accumulate(uint32_t acc, double t) {
-  const double fr = t - rint(t);
+  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
   return acc + (uint32_t)__double2loint(fr + 0x1.8p20);
 }
 template <>
 __device__ __forceinline__ uint32_t from_torus_fast<uint32_t>(double t) {
-  const double fr = t - rint(t);
+  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
   return (uint32_t)__double2loint(fr + 0x1.8p20);
 }
 

@@ -16,7 +16,8 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("w4::pbs_kernel", "wave_pbs_kernel", "block_pbs_kernel", "generic_pbs_kernel", "keyswitch_kernel")
+OURS = ("w4::pbs_kernel", "wave_pbs_kernel", "block_pbs_kernel", "generic_pbs_kernel", "keyswitch_kernel", "ks_mfma_kernel",
+        "ks_digits_kernel")
 
 
 def short(name: str) -> str | None:
@@ -68,9 +69,20 @@ def main() -> None:
                 "waiting_on_counter": avg.get("SQ_WAIT_INST_ANY", 0.0) / wc,
                 "any_instruction_active": avg.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
             }
+        if "SQ_INSTS_VALU_FMA_F64" in avg:
+            # wave-instruction counts: a wave-instruction is 64 lanes; an FMA is two flop
+            fma, add, mul = avg["SQ_INSTS_VALU_FMA_F64"], avg.get("SQ_INSTS_VALU_ADD_F64", 0.0), avg.get("SQ_INSTS_VALU_MUL_F64", 0.0)
+            entry["counted_fp64_flop"] = 64.0 * (2.0 * fma + add + mul)
+            entry["counted_fp64_instructions"] = fma + add + mul + avg.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
         if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
             entry["l2_hit_rate"] = avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
         out[k] = entry
+    # ties the summary to the kernel sources it was measured on (bench.py reports the traffic
+    # figure only while this hash matches the tree)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    out["source_hash"] = bench.kernel_source_hash()
     with open(os.path.join(dst, f"pmc_per_dispatch_{suffix}.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
