@@ -40,6 +40,44 @@ __device__ __forceinline__ uint32_t checked_lut_id(const PbsLaunch<T>& a, size_t
   return 0u;
 }
 
+// ---- rendezvous of persistent waves that share an L2 (bootstrap kernels) ----
+constexpr uint32_t WAVE_QUORUM_SLACK = 8;
+constexpr int SYNC_GROUPS = 16;         // the hardware's XCC id is a 4-bit field (MI355X has 8 XCDs)
+constexpr int SYNC_STRIDE = 32;         // counters 128 bytes apart
+constexpr size_t RENDEZVOUS_BYTES = 2 * (size_t)SYNC_GROUPS * SYNC_STRIDE * sizeof(uint32_t);
+
+// Rendezvous of the persistent waves that share an L2. Nothing is assumed about how workgroups are
+// dealt to XCDs or how many XCDs there are: every wave reads the id of the XCD it runs on from the
+// hardware register, enrols in that XCD's member count when it starts, and between ciphertexts
+// reports to that XCD's arrival counter and waits until all but 1/WAVE_QUORUM_SLACK of the members
+// have arrived. The first wait comes a whole bootstrap (milliseconds) after the launch, when every
+// workgroup of the device-sized grid has long enrolled; should a member count still be short, or a
+// wave lag, the wait is bounded and only cache behaviour is affected, never results.
+// Both counter arrays live in the key's scratch buffer and are cleared by every launch.
+struct XcdRendezvous {
+  uint32_t* arrivals;
+  uint32_t* members;
+  __device__ __forceinline__ void enrol(void* scratch, int lane) {
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): register 20, offset 0, width 4
+    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (SYNC_GROUPS - 1);
+    arrivals = (uint32_t*)scratch + xcc * SYNC_STRIDE;
+    members = arrivals + SYNC_GROUPS * SYNC_STRIDE;
+    if (lane == 0) __hip_atomic_fetch_add(members, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // after ciphertext number `round` (0-based) of this wave
+  __device__ __forceinline__ void arrive_and_wait(uint32_t round, int lane) {
+    if (lane == 0) {
+      __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t m = __hip_atomic_load(members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t target = (round + 1) * m - m / WAVE_QUORUM_SLACK;
+      for (uint32_t spin = 0; spin < (1u << 16); spin++) {
+        if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+};
 // ---- keyswitch (keyswitch.hip) ----
 template <typename T>
 int launch_keyswitch(const T* ct_in, size_t in_stride, T* ct_out, size_t out_stride, const T* ksk,

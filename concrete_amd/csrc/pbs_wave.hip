@@ -602,42 +602,7 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
 // iteration's inverse transforms), run the k+1 inverse transforms interleaved, round and add.
 // a wave moves on once all but 1/8 of its XCD's waves have arrived: waiting for the very last
 // straggler costs 1.5 % of the run, this costs nothing and keeps the fetch traffic at its minimum
-constexpr uint32_t WAVE_QUORUM_SLACK = 8;
-constexpr int SYNC_GROUPS = 16;         // the hardware's XCC id is a 4-bit field (MI355X has 8 XCDs)
-constexpr int SYNC_STRIDE = 32;         // counters 128 bytes apart
 
-// Rendezvous of the persistent waves that share an L2. Nothing is assumed about how workgroups are
-// dealt to XCDs or how many XCDs there are: every wave reads the id of the XCD it runs on from the
-// hardware register, enrols in that XCD's member count when it starts, and between ciphertexts
-// reports to that XCD's arrival counter and waits until all but 1/WAVE_QUORUM_SLACK of the members
-// have arrived. The first wait comes a whole bootstrap (milliseconds) after the launch, when every
-// workgroup of the device-sized grid has long enrolled; should a member count still be short, or a
-// wave lag, the wait is bounded and only cache behaviour is affected, never results.
-// Both counter arrays live in the key's scratch buffer and are cleared by every launch.
-struct XcdRendezvous {
-  uint32_t* arrivals;
-  uint32_t* members;
-  __device__ __forceinline__ void enrol(void* scratch, int lane) {
-    // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): register 20, offset 0, width 4
-    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (SYNC_GROUPS - 1);
-    arrivals = (uint32_t*)scratch + xcc * SYNC_STRIDE;
-    members = arrivals + SYNC_GROUPS * SYNC_STRIDE;
-    if (lane == 0) __hip_atomic_fetch_add(members, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // after ciphertext number `round` (0-based) of this wave
-  __device__ __forceinline__ void arrive_and_wait(uint32_t round, int lane) {
-    if (lane == 0) {
-      __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t m = __hip_atomic_load(members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t target = (round + 1) * m - m / WAVE_QUORUM_SLACK;
-      for (uint32_t spin = 0; spin < (1u << 16); spin++) {
-        if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-        __builtin_amdgcn_s_sleep(16);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-};
 template <typename T, int K, int BL>
 __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1;
