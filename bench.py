@@ -438,6 +438,7 @@ def main() -> None:
         achieved = count * fpp / pbs_s / 1e12 if pbs_s > 0 else 0.0
         traffic, provenance = (measured_traffic("wave_pbs_kernel") if dk.variant == 2 and count == 1 << 14
                                else (None, {"from_profile": None}))
+        measured_peak = ctx.measure_fp64_fma_rate()   # 5 ms probe: what v_fma_f64 sustains on this GPU right now
         ks_macs = p.glwe_dimension * p.polynomial_size * p.ks_level * (p.lwe_dimension + 1)
         line = {
             "metric": "bootstraps/sec (node), MESSAGE_2_CARRY_2",
@@ -468,6 +469,8 @@ def main() -> None:
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS,
+                "measured_fp64_fma_peak": measured_peak,
+                "frac_of_measured_peak": achieved / measured_peak if measured_peak > 0 else None,
                 "traffic": traffic,
                 "traffic_provenance": provenance,
                 "traffic_unit": "bytes per launch past the L2 (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, "
@@ -481,6 +484,8 @@ def main() -> None:
                 "note": "bound: f64 vector ALU (not the matrix cores: per frequency the contraction is a 3x3 complex "
                         "matrix times one vector). peak = 78.6 TFLOP/s is the vendor's FP64 vector figure (256 CUs x 4 "
                         "SIMDs x 16 FMA lanes x 2.4 GHz); the microarchitecture guide of this image has no FP64 row. "
+                        "measured_fp64_fma_peak is what independent v_fma_f64 chains sustain on this GPU in this run "
+                        "(the chip holds 1.8-2.0 GHz under a dense FP64 load); frac stays the fraction of the datasheet figure. "
                         "keyswitch_int_ops_per_s counts wrapping u64 multiply-adds and is not part of the FP64 fraction",
             },
             # outputs that do not decrypt to f(m). The parameter set itself fails with probability

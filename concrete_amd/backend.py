@@ -44,6 +44,12 @@ class Context:
             int(alpha) & mask, C.c_void_p(y.data_ptr()) if y is not None else None, y.stride(0) if y is not None else 0,
             int(beta) & mask, int(body_add) & mask, out.shape[1], out.shape[0], C.c_void_p(stream)))
 
+    def measure_fp64_fma_rate(self) -> float:
+        """Sustained v_fma_f64 rate of this GPU in TFLOP/s (a 5 ms probe kernel)."""
+        t = C.c_double()
+        check(_ffi.lib().camd_measure_fp64_fma_rate(self._h, C.byref(t)))
+        return t.value
+
     def close(self) -> None:
         if self._h:
             _ffi.lib().camd_context_destroy(self._h)

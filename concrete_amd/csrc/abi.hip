@@ -965,6 +965,13 @@ int camd_lwe_axpby_device(camd_context* ctx, uint32_t torus_bits, void* out, siz
                                     (const uint32_t*)y, y_stride, (uint32_t)beta, (uint32_t)body_add, words, count, s);
 }
 
+int camd_measure_fp64_fma_rate(camd_context* ctx, double* tflops) {
+  if (!ctx || !tflops) return fail(CAMD_EINVAL, "null argument");
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(CAMD_EHIP, "hipSetDevice failed");
+  return measure_fp64_fma_rate(ctx->stream, tflops);
+}
+
 int camd_timing_enable(camd_server_key* key, int enable) {
   if (!key) return fail(CAMD_EINVAL, "null key");
   DeviceGuard g(key->ctx->device);

@@ -97,6 +97,9 @@ int launch_keyswitch_mfma(const T* ct_in, size_t in_stride, T* ct_out, size_t ou
                           int8_t* digits, uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level, size_t count,
                           hipStream_t stream);
 
+// ---- measurement helper (probe.hip): sustained v_fma_f64 rate of the current device ----
+int measure_fp64_fma_rate(hipStream_t stream, double* tflops);
+
 // ---- leveled operations on device ciphertexts (linear.hip) ----
 template <typename T>
 int launch_lwe_axpby(T* out, size_t out_stride, const T* x, size_t x_stride, T alpha, const T* y, size_t y_stride, T beta,

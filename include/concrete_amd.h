@@ -200,6 +200,9 @@ int camd_lwe_axpby_device(camd_context* ctx, uint32_t torus_bits, void* out, siz
  * over the launches made since the last reset, taken with HIP events on the stream the
  * kernels were launched on. Timing is off by default (enable != 0 turns it on). */
 int camd_timing_enable(camd_server_key* key, int enable);
+/* The FP64 fused-multiply-add rate the GPU of `ctx` sustains, in TFLOP/s (independent v_fma_f64
+ * chains on every SIMD for about 5 ms): a measured ceiling to set beside the datasheet's. */
+int camd_measure_fp64_fma_rate(camd_context* ctx, double* tflops);
 int camd_timing_read(camd_server_key* key, double* pbs_ms_avg, uint64_t* pbs_launches,
                      double* ks_ms_avg, uint64_t* ks_launches);
 

@@ -4,7 +4,7 @@ use std::env;
 use std::path::PathBuf;
 use std::process::Command;
 
-const SOURCES: [&str; 8] = [
+const SOURCES: [&str; 9] = [
     "abi.hip",
     "keyswitch.hip",
     "keyswitch_mfma.hip",
@@ -12,6 +12,7 @@ const SOURCES: [&str; 8] = [
     "pbs_generic.hip",
     "pbs_block.hip",
     "pbs_wave.hip",
+    "probe.hip",
     "client.cpp",
 ];
 
