@@ -71,6 +71,7 @@ def measured_traffic(kernel: str):
                 "source_hash": kernel_source_hash()}
         if doc.get("source_hash") != prov["source_hash"]:
             return None, dict(prov, stale=True)
+        prov["counted_fp64_flop_per_launch"] = e.get("counted_fp64_flop")
         return float(e["hbm_fetch_bytes"] + e["hbm_write_bytes"]), prov
     except (OSError, KeyError, ValueError):
         return None, {"from_profile": None}
@@ -473,6 +474,12 @@ def main() -> None:
                 "frac_of_measured_peak": achieved / measured_peak if measured_peak > 0 else None,
                 "traffic": traffic,
                 "traffic_provenance": provenance,
+                # cross-check of `achieved`: f64 instructions the kernel really executed (rocprofv3
+                # SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 of the committed profile, 64 lanes, FMA = 2 flop) over the
+                # duration measured in this run; below the algorithmic figure because radix-8 butterflies
+                # need fewer operations than the 5 M log2 M convention charges
+                "executed_fp64_tflops": (provenance.get("counted_fp64_flop_per_launch") / pbs_s / 1e12
+                                         if traffic is not None and provenance.get("counted_fp64_flop_per_launch") and pbs_s > 0 else None),
                 "traffic_unit": "bytes per launch past the L2 (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, "
                                 "from the committed summary; null when the kernel sources changed since); the Fourier "
                                 "key is 56.7 MB and stays in the Infinity Cache, so this is fabric, not HBM, traffic",
