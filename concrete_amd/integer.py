@@ -428,14 +428,20 @@ class ServerKey(CrtServerOps):
     def blockshift(self, ctxt: RadixCiphertext, shift: int) -> RadixCiphertext:
         """radix/scalar_mul.rs:280-292: multiply by message_modulus^shift (high blocks fall off)."""
         n = len(ctxt.blocks)
+        if shift < 0:
+            raise ValueError("blockshift: negative shift")
+        shift = min(int(shift), n)   # shifting by the whole width or more leaves zeros only
         zero = self.key.create_trivial(0, like=ctxt.blocks[0])
-        return RadixCiphertext([zero.clone() for _ in range(min(shift, n))] + [b.clone() for b in ctxt.blocks[:n - shift]])
+        return RadixCiphertext([zero.clone() for _ in range(shift)] + [b.clone() for b in ctxt.blocks[:n - shift]])
 
     def blockshift_right(self, ctxt: RadixCiphertext, shift: int) -> RadixCiphertext:
         """radix/shift.rs:33-46."""
         n = len(ctxt.blocks)
+        if shift < 0:
+            raise ValueError("blockshift_right: negative shift")
+        shift = min(int(shift), n)
         zero = self.key.create_trivial(0, like=ctxt.blocks[0])
-        return RadixCiphertext([b.clone() for b in ctxt.blocks[shift:]] + [zero.clone() for _ in range(min(shift, n))])
+        return RadixCiphertext([b.clone() for b in ctxt.blocks[shift:]] + [zero.clone() for _ in range(shift)])
 
     def smart_scalar_mul(self, ctxt: RadixCiphertext, scalar: int) -> RadixCiphertext:
         """radix/scalar_mul.rs:316-358: one small-scalar product per distinct non-trivial digit of

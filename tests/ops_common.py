@@ -256,6 +256,13 @@ def check_radix_ops(cks, sks, count=6, device=False, seed=3, num_blocks=4, tally
     for sh in (1, 2, 3, 5):
         t.eq(dec(isks.unchecked_scalar_left_shift(cx.clone(), sh)), (x << np.uint64(sh)) % mod)
         t.eq(dec(isks.unchecked_scalar_right_shift(cx.clone(), sh)), x >> np.uint64(sh))
+    # block shifts by the whole width or more leave zeros and keep the block count (radix/scalar_mul.rs:280-292)
+    nb = len(cx.blocks)
+    for sh in (0, 1, nb, nb + 3):
+        left, right = isks.blockshift(cx.clone(), sh), isks.blockshift_right(cx.clone(), sh)
+        assert len(left.blocks) == nb and len(right.blocks) == nb
+        t.eq(dec(left), (x << np.uint64(2 * min(sh, nb))) % mod if sh < nb else x * 0)
+        t.eq(dec(right), x >> np.uint64(2 * min(sh, nb)) if sh < nb else x * 0)
     # single integers go through the same code (reference signatures)
     one = icks.encrypt(201)
     two = icks.encrypt(77)
