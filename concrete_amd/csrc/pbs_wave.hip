@@ -168,14 +168,6 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
   dft8<true>(x);
 }
 
-// wrapping add of a 64-bit (hi, lo) pair into a torus word, on the dword halves
-__device__ __forceinline__ uint64_t add_halves(uint64_t acc, uint32_t hi, uint32_t lo) {
-  const uint32_t alo = (uint32_t)acc, ahi = (uint32_t)(acc >> 32);
-  const uint32_t rlo = alo + lo;
-  const uint32_t rhi = ahi + hi + (rlo < lo ? 1u : 0u);
-  return ((uint64_t)rhi << 32) | rlo;
-}
-
 // f64 (torus units) -> torus word by magic-constant additions: with fr = t mod 1 in [0, 1), adding
 // 1.5*2^20 leaves round(fr*2^32) in the low dword of the sum (a carry out of it is a whole turn of
 // the torus); the remainder, added to 1.5*2^-12, leaves round(rem*2^64) in its mantissa.
@@ -192,39 +184,37 @@ __device__ __forceinline__ uint64_t from_torus_fast<uint64_t>(double t) {
   const uint32_t hi = q + (uint32_t)((__double2hiint(b) & 0xFFFFF) - 0x80000);
   return ((uint64_t)hi << 32) | lo;
 }
-// acc += from_torus_fast(t), without assembling the 64-bit word first
-__device__ __forceinline__ uint64_t torus_accumulate(uint64_t acc, double t) {
-  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
-  const double a = fr + 0x1.8p20;
-  const uint32_t q = (uint32_t)__double2loint(a);
-  const double rem = fr - (a - 0x1.8p20);
-  const double b = rem + 0x1.8p-12;
-  const uint32_t lo = (uint32_t)__double2loint(b);
-  const uint32_t hi = q + (uint32_t)((__double2hiint(b) & 0xFFFFF) - 0x80000);
-  return add_halves(acc, hi, lo);
-}
-// The same sum in two steps, so that a caller can separate the carry's producer from its
-// consumer. The second magic addition leaves b in [1.5*2^-12 - 2^-33, 1.5*2^-12 + 2^-33]: its
-// exponent field is constant, and (high dword of b & 0xFFFFF) - 0x80000 is the high dword minus
-// 0x3F380000; that constant is added together with the carry.
+// acc += t (torus units) rounded to 52 fractional bits, in four instructions. With fr = t mod 1,
+// b = 1 + fr has the exponent of 1.0, or is exactly 2.0, so its mantissa m is fr in units of 2^-52
+// (zero for b = 2.0: a whole turn) and the addend is m << 12: the low dword of b times 2^12 goes in
+// as a 32 x 32 + 64 bit multiply-add, the 20 mantissa bits of the high dword are shifted to the top
+// of the high dword, where the exponent bits fall off. The 12 bits this drops are 2^-52 of the
+// torus, five orders of magnitude below what the f64 transforms themselves leave in a coefficient.
+// The two instructions are written out: the compiler rebuilds the shift from the 64-bit pattern in
+// three instructions and has no pattern for a multiply-add by a power of two. They are separate
+// calls because v_mad_u64_u32 costs an idle slot when it reads a register written by the
+// instruction before it: a caller with several sums in flight does all the first halves first.
 struct TorusSum {
-  uint32_t lo, hi_partial;
-  bool carry;
+  uint64_t partial;   // acc with the top 20 mantissa bits added into the high dword
+  uint32_t low;       // low dword of b = 1 + (t mod 1)
 };
-__device__ __forceinline__ TorusSum torus_accumulate_low(uint64_t acc, double t) {
-  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
-  const double a = fr + 0x1.8p20;
-  const uint32_t q = (uint32_t)__double2loint(a);
-  const double rem = fr - (a - 0x1.8p20);
-  const double b = rem + 0x1.8p-12;
+__device__ __forceinline__ TorusSum torus_accumulate_begin(uint64_t acc, double t) {
+  const double b = __builtin_amdgcn_fract(t) + 1.0;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 w = __builtin_bit_cast(u32x2, acc);
+  asm("v_lshl_add_u32 %0, %1, 12, %0" : "+v"(w.y) : "v"(__double2hiint(b)));
   TorusSum s;
-  s.carry = __builtin_add_overflow((uint32_t)acc, (uint32_t)__double2loint(b), &s.lo);
-  s.hi_partial = (uint32_t)(acc >> 32) + q + (uint32_t)__double2hiint(b);
+  s.partial = __builtin_bit_cast(uint64_t, w);
+  s.low = (uint32_t)__double2loint(b);
   return s;
 }
-__device__ __forceinline__ uint64_t torus_accumulate_high(const TorusSum& s) {
-  const uint32_t hi = s.hi_partial + 0xC0C80000u + (uint32_t)s.carry;  // -0x3F380000
-  return ((uint64_t)hi << 32) | s.lo;
+__device__ __forceinline__ uint64_t torus_accumulate_end(const TorusSum& s) {
+  uint64_t r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(s.low), "s"(4096u), "v"(s.partial) : "vcc");
+  return r;
+}
+__device__ __forceinline__ uint64_t torus_accumulate(uint64_t acc, double t) {
+  return torus_accumulate_end(torus_accumulate_begin(acc, t));
 }
 __device__ __forceinline__ uint32_t torus_accumulate(uint32_t acc, double t) {
   const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
@@ -711,45 +701,25 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           twg[u & 1][t] = tab[TAB_TWIST + j0];
         }
       };
-      // The 64-bit negation and subtraction are carry chains through a scalar register pair, and
-      // a vector instruction may not read such a pair within two issue slots of the instruction
-      // that wrote it: left to the compiler every chain costs an idle slot. Here the low halves
-      // of all eight coefficients of a unit are issued first, then the high halves.
+      // Only the high dwords enter: r - own with r = wrapped ? -rot : rot has the high dword
+      // (rot_hi ^ m) - own_hi with m = 0 or all ones, up to the borrow of the low halves (and the
+      // +1 of a negation whose low dword is zero). The digit is that value rounded at bit 32 - BL,
+      // so leaving the borrow out moves the rounded value by at most 2^-32 of the torus against a
+      // rounding step of 2^-BL: the decomposition error bound B^-1/2 grows by a factor 1 + 2^(BL-31).
+      // The rounding is an arithmetic shift: digits in [-B/2, B/2) where the generic form has
+      // (-B/2, B/2]; the two ends are the same residue.
       auto consume = [&](int u) {
         if constexpr (sizeof(T) == 8) {
-          // r = wrapped ? -rot : rot, as (rot ^ m) - m with m = 0 or all ones (two's complement
-          // negation is complement plus one): no selects, one borrow chain
-          uint32_t msk[4][2], xhi[4][2], rlo[4][2];
-          bool rb[4][2];
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const uint32_t j0 = 64 * (4 * (u & 1) + t) + lane, j1 = j0 + M;
-            msk[t][0] = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(j0 - a_hat), LOGN, 1);
-            msk[t][1] = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(j1 - a_hat), LOGN, 1);
-            xhi[t][0] = (uint32_t)(rot0[u & 1][t] >> 32) ^ msk[t][0];
-            xhi[t][1] = (uint32_t)(rot1[u & 1][t] >> 32) ^ msk[t][1];
-            rb[t][0] = __builtin_sub_overflow((uint32_t)rot0[u & 1][t] ^ msk[t][0], msk[t][0], &rlo[t][0]);
-            rb[t][1] = __builtin_sub_overflow((uint32_t)rot1[u & 1][t] ^ msk[t][1], msk[t][1], &rlo[t][1]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          uint32_t rhi[4][2];
-          bool db[4][2];
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            rhi[t][0] = xhi[t][0] - msk[t][0] - (uint32_t)rb[t][0];
-            rhi[t][1] = xhi[t][1] - msk[t][1] - (uint32_t)rb[t][1];
-            // only the borrow of the low half of r - own is needed: the digit lies in the high dword
-            db[t][0] = rlo[t][0] < (uint32_t)own0[u & 1][t];
-            db[t][1] = rlo[t][1] < (uint32_t)own1[u & 1][t];
-          }
-          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t = 0; t < 4; t++) {
             const int q = 4 * (u & 1) + t;
-            const uint32_t d0 = rhi[t][0] - (uint32_t)(own0[u & 1][t] >> 32) - (uint32_t)db[t][0];
-            const uint32_t d1 = rhi[t][1] - (uint32_t)(own1[u & 1][t] >> 32) - (uint32_t)db[t][1];
-            const int32_t g0 = digit_single32<T, BL>((T)d0 << 32);
-            const int32_t g1 = digit_single32<T, BL>((T)d1 << 32);
+            const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(j0 - a_hat), LOGN, 1);
+            const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(j1 - a_hat), LOGN, 1);
+            constexpr uint32_t HALF = 1u << (32 - BL - 1);
+            const uint32_t d0 = (((uint32_t)(rot0[u & 1][t] >> 32) ^ m0) + HALF) - (uint32_t)(own0[u & 1][t] >> 32);
+            const uint32_t d1 = (((uint32_t)(rot1[u & 1][t] >> 32) ^ m1) + HALF) - (uint32_t)(own1[u & 1][t] >> 32);
+            const int32_t g0 = (int32_t)d0 >> (32 - BL), g1 = (int32_t)d1 >> (32 - BL);
             x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), twg[u & 1][t]);
           }
         } else {
@@ -887,22 +857,22 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
         __builtin_amdgcn_sched_barrier(0);
         T* pc = ct0 + c * N;
         if constexpr (sizeof(T) == 8) {
-          // low halves (and their carries) of all sixteen sums first, high halves afterwards: the
-          // carry registers are then read at a distance and cost no idle slots
-          TorusSum sum[8][2];
+          // one coefficient pair behind: the multiply-adds of pair q-1 sit between the arithmetic
+          // of pair q (two of them back to back cost an idle slot as well)
+          TorusSum prev0, prev1;
 #pragma unroll
           for (int q = 0; q < 8; q++) {
             const double2 v = cmul_conj(acc[c][q], twr[c & 1][q]);
-            sum[q][0] = torus_accumulate_low(old0[c & 1][q], v.x);
-            sum[q][1] = torus_accumulate_low(old1[c & 1][q], v.y);
+            const TorusSum cur0 = torus_accumulate_begin(old0[c & 1][q], v.x);
+            if (q > 0) pc[64 * (q - 1) + lane] = torus_accumulate_end(prev0);
+            const TorusSum cur1 = torus_accumulate_begin(old1[c & 1][q], v.y);
+            if (q > 0) pc[64 * (q - 1) + lane + M] = torus_accumulate_end(prev1);
+            prev0 = cur0;
+            prev1 = cur1;
           }
+          pc[64 * 7 + lane] = torus_accumulate_end(prev0);
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < 8; q++) {
-            const uint32_t j0 = 64 * q + lane;
-            pc[j0] = torus_accumulate_high(sum[q][0]);
-            pc[j0 + M] = torus_accumulate_high(sum[q][1]);
-          }
+          pc[64 * 7 + lane + M] = torus_accumulate_end(prev1);
         } else {
 #pragma unroll
           for (int q = 0; q < 8; q++) {

@@ -168,11 +168,13 @@ class ServerKey(CrtServerOps):
         carries = []
         with self.key.deferred():
             for ctxt, index in pairs:
-                carry = self.key.carry_extract(ctxt.blocks[index])
+                # radix/mod.rs:58-68 extracts the carry of the last block too and then drops it;
+                # that bootstrap has no effect on any output, so it is not launched.
+                last = index >= len(ctxt.blocks) - 1
+                carries.append(None if last else self.key.carry_extract(ctxt.blocks[index]))
                 self.key.message_extract_assign(ctxt.blocks[index])
-                carries.append(carry)
         for (ctxt, index), carry in zip(pairs, carries):
-            if index < len(ctxt.blocks) - 1:
+            if carry is not None:
                 self.key.unchecked_add_assign(ctxt.blocks[index + 1], carry)
 
     def propagate(self, ctxt: RadixCiphertext, index: int) -> None:
