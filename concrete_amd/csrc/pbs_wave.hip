@@ -43,9 +43,24 @@ constexpr int PLANE = RADIX * ROW;
 constexpr int TAB_TWIST = 0;                   // [a][lane]  e^{+i pi (64a+lane)/N}
 constexpr int TAB_TW0 = 512;                   // [b-1][lane] e^{-2 pi i lane b / 512}, b = 1..7
 constexpr int TAB_TW1 = TAB_TW0 + 7 * 64;      // [b-1][m]    e^{-2 pi i m b / 64},    b = 1..7, m < 8
-constexpr int TAB_COUNT = TAB_TW1 + 7 * 8;
+constexpr int TAB_COUNT = TAB_TW1 + 7 * 8;     // what the one-transform-at-a-time kernels stage in LDS
+// The interleaved-transform kernel splits the twist e^{i pi (64a+lane)/N} into a per-register part
+// e^{i pi a/16}, eight compile-time constants, and a per-lane part e^{i pi lane/N}. The per-lane part
+// commutes with the first radix-8 pass (it is the same for the eight inputs of a lane), so it is
+// folded into that pass's output twiddles: [b][lane] e^{i pi lane (1 - 4b)/N}, b = 0..7. No twist
+// table is read at all, for the same number of multiplications.
+constexpr int TAB_TW0T = TAB_COUNT;
+constexpr int TAB_TOTAL = TAB_TW0T + 8 * 64;
+constexpr int TABV2_TW0T = 0, TABV2_TW1 = 8 * 64, TABV2_COUNT = TABV2_TW1 + 7 * 8;   // that kernel's own LDS image
 
 constexpr double HALF_SQRT2 = 0.70710678118654752440;
+// e^{i pi a / 16}, a = 0..7
+constexpr double TWIST8_RE[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                 0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                                 0.19509032201612826785};
+constexpr double TWIST8_IM[8] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
+                                 0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613,
+                                 0.98078528040323044913};
 
 // Small batches go to the kernels that give a ciphertext k+1 waves: up to `fit` ciphertexts per
 // CU, where `fit` is the number of such workgroups a CU holds at once. CAMD_WAVE_LATENCY=0 keeps
@@ -278,6 +293,32 @@ __device__ __forceinline__ int32_t digit_single32(T x) {
   }
 }
 
+// Signed single-level digit of (wrapped ? -rot : rot) - own, where `shifted` = j - a_hat carries the
+// wrap in bit LOGN. For a 64-bit torus whose digit lies in the high dword only the high dwords
+// enter: the difference has the high dword (rot_hi ^ m) - own_hi with m = 0 or all ones, up to the
+// borrow of the low halves (and the +1 of a negation whose low dword is zero). The digit is that
+// value rounded at bit 32 - BL, so leaving the borrow out moves the value being rounded by at most
+// 2^-32 of the torus against a rounding step of 2^-BL: the decomposition error bound B^-1/2 grows
+// by a factor 1 + 2^(BL-31). The rounding is an arithmetic shift: digits in [-B/2, B/2) where the
+// generic form has (-B/2, B/2]; the two ends are the same residue.
+template <typename T, int BL, int LOGN>
+__device__ __forceinline__ int32_t digit_of_rotated_difference(T rot, T own, uint32_t shifted) {
+  if constexpr (sizeof(T) == 8 && BL <= 31) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int32_t)shifted, LOGN, 1);
+    constexpr uint32_t HALF = 1u << (32 - BL - 1);
+#ifdef CAMD_NO_XAD
+    const uint32_t d = ((uint32_t)(rot >> 32) ^ m) + HALF;
+#else
+    uint32_t d;   // (rot_hi ^ m) + HALF in one instruction; the compiler reassociates the sum and loses the pattern
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"((uint32_t)(rot >> 32)), "v"(m), "s"(HALF));
+#endif
+    return (int32_t)(d - (uint32_t)(own >> 32)) >> (32 - BL);
+  } else {
+    const T r = ((shifted >> LOGN) & 1u) ? (T)(T(0) - rot) : rot;
+    return digit_single32<T, BL>((T)(r - own));
+  }
+}
+
 // broadcast lane 0's value through SGPRs so that the compiler sees a wave-uniform value
 __device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -293,6 +334,10 @@ constexpr size_t wave_slab_bytes() {
 template <typename T, int K>
 constexpr size_t wave_lds_bytes() {
   return TAB_COUNT * sizeof(double2) + WAVES * wave_slab_bytes<T, K>();
+}
+template <typename T, int K>
+constexpr size_t wave_v2_lds_bytes() {
+  return TABV2_COUNT * sizeof(double2) + WAVES * wave_slab_bytes<T, K>();
 }
 
 // ---- key conversion: one wave per polynomial, same transform, key pre-scaled by 1/512 ----
@@ -491,14 +536,14 @@ template <int S>
 __device__ __forceinline__ void fft512_forward_multi(double2 (&x)[S][8], int lane, const double2* tab, double* sre,
                                                      double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
-  double2 w[7];
+  double2 w[8];
 #pragma unroll
-  for (int b = 1; b < 8; b++) w[b - 1] = tab[TAB_TW0 + (b - 1) * 64 + lane];
+  for (int b = 0; b < 8; b++) w[b] = tab[TABV2_TW0T + b * 64 + lane];
 #pragma unroll
   for (int s = 0; s < S; s++) {
     dft8<false>(x[s]);
 #pragma unroll
-    for (int b = 1; b < 8; b++) x[s][b] = cmul(x[s][b], w[b - 1]);
+    for (int b = 0; b < 8; b++) x[s][b] = cmul(x[s][b], w[b]);
   }
 #pragma unroll
   for (int s = 0; s < S; s++) {
@@ -513,12 +558,12 @@ __device__ __forceinline__ void fft512_forward_multi(double2 (&x)[S][8], int lan
     }
   }
 #pragma unroll
-  for (int b = 1; b < 8; b++) w[b - 1] = tab[TAB_TW1 + (b - 1) * 8 + lo];
+  for (int b = 1; b < 8; b++) w[b] = tab[TABV2_TW1 + (b - 1) * 8 + lo];
 #pragma unroll
   for (int s = 0; s < S; s++) {
     dft8<false>(x[s]);
 #pragma unroll
-    for (int b = 1; b < 8; b++) x[s][b] = cmul(x[s][b], w[b - 1]);
+    for (int b = 1; b < 8; b++) x[s][b] = cmul(x[s][b], w[b]);
   }
 #pragma unroll
   for (int s = 0; s < S; s++) {
@@ -547,12 +592,12 @@ template <int S, typename Hook = NoHook>
 __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lane, const double2* tab, double* sre,
                                                      double* sim, Hook hook = Hook()) {
   const int hi = lane >> 3, lo = lane & 7;
-  double2 w[7];
+  double2 w[8];
   hook(0);
 #pragma unroll
   for (int s = 0; s < S; s++) dft8<true>(x[s]);
 #pragma unroll
-  for (int b = 1; b < 8; b++) w[b - 1] = tab[TAB_TW1 + (b - 1) * 8 + lo];
+  for (int b = 1; b < 8; b++) w[b] = tab[TABV2_TW1 + (b - 1) * 8 + lo];
 #pragma unroll
   for (int s = 0; s < S; s++) {
 #pragma unroll
@@ -570,11 +615,11 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
 #pragma unroll
   for (int s = 0; s < S; s++) {
 #pragma unroll
-    for (int b = 1; b < 8; b++) x[s][b] = cmul_conj(x[s][b], w[b - 1]);
+    for (int b = 1; b < 8; b++) x[s][b] = cmul_conj(x[s][b], w[b]);
     dft8<true>(x[s]);
   }
 #pragma unroll
-  for (int b = 1; b < 8; b++) w[b - 1] = tab[TAB_TW0 + (b - 1) * 64 + lane];
+  for (int b = 0; b < 8; b++) w[b] = tab[TABV2_TW0T + b * 64 + lane];
 #pragma unroll
   for (int s = 0; s < S; s++) {
 #pragma unroll
@@ -589,7 +634,7 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
 #pragma unroll
   for (int s = 0; s < S; s++) {
 #pragma unroll
-    for (int b = 1; b < 8; b++) x[s][b] = cmul_conj(x[s][b], w[b - 1]);
+    for (int b = 0; b < 8; b++) x[s][b] = cmul_conj(x[s][b], w[b]);
     dft8<true>(x[s]);
   }
 }
@@ -606,12 +651,13 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = a.tables[t];
+  for (int t = threadIdx.x; t < TABV2_COUNT; t += 256)
+    tab[t] = a.tables[t < TABV2_TW1 ? TAB_TW0T + t : TAB_TW1 + (t - TABV2_TW1)];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
+  char* slab = smem + TABV2_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
   T* ct0 = (T*)slab;
   double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
   double* sim = sre + PLANE;
@@ -688,7 +734,6 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
       // of half a polynomial, one unit ahead of the arithmetic that consumes them, and the
       // order is pinned so that the latency of a unit hides behind the previous unit's work.
       T own0[2][4], own1[2][4], rot0[2][4], rot1[2][4];
-      double2 twg[2][4];  // twist factors travel with the unit: no table read inside the arithmetic
       auto issue = [&](int u) {
         const T* p = ct0 + (u >> 1) * N;
 #pragma unroll
@@ -698,41 +743,18 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           own1[u & 1][t] = p[j1];
           rot0[u & 1][t] = p[(j0 - a_hat) & (N - 1)];
           rot1[u & 1][t] = p[(j1 - a_hat) & (N - 1)];
-          twg[u & 1][t] = tab[TAB_TWIST + j0];
         }
       };
-      // Only the high dwords enter: r - own with r = wrapped ? -rot : rot has the high dword
-      // (rot_hi ^ m) - own_hi with m = 0 or all ones, up to the borrow of the low halves (and the
-      // +1 of a negation whose low dword is zero). The digit is that value rounded at bit 32 - BL,
-      // so leaving the borrow out moves the rounded value by at most 2^-32 of the torus against a
-      // rounding step of 2^-BL: the decomposition error bound B^-1/2 grows by a factor 1 + 2^(BL-31).
-      // The rounding is an arithmetic shift: digits in [-B/2, B/2) where the generic form has
-      // (-B/2, B/2]; the two ends are the same residue.
       auto consume = [&](int u) {
-        if constexpr (sizeof(T) == 8) {
 #pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const int q = 4 * (u & 1) + t;
-            const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-            const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(j0 - a_hat), LOGN, 1);
-            const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(j1 - a_hat), LOGN, 1);
-            constexpr uint32_t HALF = 1u << (32 - BL - 1);
-            const uint32_t d0 = (((uint32_t)(rot0[u & 1][t] >> 32) ^ m0) + HALF) - (uint32_t)(own0[u & 1][t] >> 32);
-            const uint32_t d1 = (((uint32_t)(rot1[u & 1][t] >> 32) ^ m1) + HALF) - (uint32_t)(own1[u & 1][t] >> 32);
-            const int32_t g0 = (int32_t)d0 >> (32 - BL), g1 = (int32_t)d1 >> (32 - BL);
-            x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), twg[u & 1][t]);
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const int q = 4 * (u & 1) + t;
-            const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-            const T r0 = ((j0 - a_hat) & N) ? (T)(T(0) - rot0[u & 1][t]) : rot0[u & 1][t];
-            const T r1 = ((j1 - a_hat) & N) ? (T)(T(0) - rot1[u & 1][t]) : rot1[u & 1][t];
-            const int32_t g0 = digit_single32<T, BL>((T)(r0 - own0[u & 1][t]));
-            const int32_t g1 = digit_single32<T, BL>((T)(r1 - own1[u & 1][t]));
-            x[u >> 1][q] = cmul(make_double2((double)g0, (double)g1), twg[u & 1][t]);
-          }
+        for (int t = 0; t < 4; t++) {
+          const int q = 4 * (u & 1) + t;
+          const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+          const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0[u & 1][t], own0[u & 1][t], j0 - a_hat);
+          const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1[u & 1][t], own1[u & 1][t], j1 - a_hat);
+          // the per-register part of the twist; the per-lane part is in the transform's twiddles
+          const double2 d = make_double2((double)g0, (double)g1);
+          x[u >> 1][q] = q == 0 ? d : cmul(d, make_double2(TWIST8_RE[q], TWIST8_IM[q]));
         }
       };
       issue(0);
@@ -838,14 +860,12 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
       STAMP(tI)
       // untwist, round, add into the accumulator: old values are read one column ahead
       T old0[2][8], old1[2][8];
-      double2 twr[2][8];
       auto issue_old = [&](int c) {
         const T* pc = ct0 + c * N;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           old0[c & 1][q] = pc[64 * q + lane];
           old1[c & 1][q] = pc[64 * q + lane + M];
-          twr[c & 1][q] = tab[TAB_TWIST + 64 * q + lane];
         }
       };
       issue_old(0);
@@ -862,7 +882,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           TorusSum prev0, prev1;
 #pragma unroll
           for (int q = 0; q < 8; q++) {
-            const double2 v = cmul_conj(acc[c][q], twr[c & 1][q]);
+            const double2 v = q == 0 ? acc[c][q] : cmul_conj(acc[c][q], make_double2(TWIST8_RE[q], TWIST8_IM[q]));
             const TorusSum cur0 = torus_accumulate_begin(old0[c & 1][q], v.x);
             if (q > 0) pc[64 * (q - 1) + lane] = torus_accumulate_end(prev0);
             const TorusSum cur1 = torus_accumulate_begin(old1[c & 1][q], v.y);
@@ -877,7 +897,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
 #pragma unroll
           for (int q = 0; q < 8; q++) {
             const uint32_t j0 = 64 * q + lane;
-            const double2 v = cmul_conj(acc[c][q], twr[c & 1][q]);
+            const double2 v = q == 0 ? acc[c][q] : cmul_conj(acc[c][q], make_double2(TWIST8_RE[q], TWIST8_IM[q]));
             pc[j0] = torus_accumulate(old0[c & 1][q], v.x);
             pc[j0 + M] = torus_accumulate(old1[c & 1][q], v.y);
           }
@@ -1285,14 +1305,14 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
             const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
             const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
             const T rot0 = p[s0 & (N - 1)], rot1 = p[s1 & (N - 1)];
-            const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
-            const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
             const double2 tw = tab[TAB_TWIST + j0];
             if constexpr (L == 1) {
-              const int32_t g0 = digit_single32<T, BL>((T)(r0 - p[j0]));
-              const int32_t g1 = digit_single32<T, BL>((T)(r1 - p[j1]));
+              const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, p[j0], s0);
+              const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, p[j1], s1);
               x[r][q] = cmul(make_double2((double)g0, (double)g1), tw);
             } else {
+              const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
+              const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
               uint32_t st0 = digit_state32<T, BL, L>((T)(r0 - p[j0]));
               uint32_t st1 = digit_state32<T, BL, L>((T)(r1 - p[j1]));
 #pragma unroll
@@ -1466,14 +1486,14 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
         const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
         const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
         const T rot0 = stage[s0 & (N - 1)], rot1 = stage[s1 & (N - 1)];
-        const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
-        const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
         const double2 tw = tab[TAB_TWIST + j0];
         if constexpr (L == 1) {
-          const int32_t g0 = digit_single32<T, BL>((T)(r0 - acc[2 * q]));
-          const int32_t g1 = digit_single32<T, BL>((T)(r1 - acc[2 * q + 1]));
+          const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, acc[2 * q], s0);
+          const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, acc[2 * q + 1], s1);
           x[0][q] = cmul(make_double2((double)g0, (double)g1), tw);
         } else {
+          const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
+          const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
           uint32_t st0 = digit_state32<T, BL, L>((T)(r0 - acc[2 * q]));
           uint32_t st1 = digit_state32<T, BL, L>((T)(r1 - acc[2 * q + 1]));
 #pragma unroll
@@ -1611,7 +1631,8 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
   if constexpr (L == 1) {
     if (schedule == 2) {
       auto kern2 = wave_pbs_kernel_v2<T, K, BL>;
-      CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      constexpr size_t lds2 = wave_v2_lds_bytes<T, K>();
+      CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
       int dev = 0, cus = 0;
       CAMD_HIP(hipGetDevice(&dev));
       CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1620,7 +1641,7 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
         if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
         CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
       }
-      hipLaunchKernelGGL(kern2, dim3(persistent), dim3(256), lds, stream, a);
+      hipLaunchKernelGGL(kern2, dim3(persistent), dim3(256), lds2, stream, a);
       CAMD_HIP(hipGetLastError());
       return CAMD_OK;
     }
@@ -1652,7 +1673,7 @@ static bool tfhe_lib_instance(const camd_params& p) {
 
 bool wave_supported(const camd_params& p) { return wave_default(p) || w4::supported(p) || tfhe_lib_instance(p); }
 
-size_t wave_tables_count(uint32_t N) { return N == 512 ? (size_t)w4::TAB_COUNT : (size_t)TAB_COUNT; }
+size_t wave_tables_count(uint32_t N) { return N == 512 ? (size_t)w4::TAB_COUNT : (size_t)TAB_TOTAL; }
 
 void wave_fill_tables(uint32_t N, double2* t) {
   if (N == 512) {
@@ -1672,6 +1693,11 @@ void wave_fill_tables(uint32_t N, double2* t) {
     for (int m = 0; m < 8; m++) {
       const double ang = -2.0 * M_PI * (double)(m * b) / 64.0;
       t[TAB_TW1 + (b - 1) * 8 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+  for (int b = 0; b < 8; b++)
+    for (int m = 0; m < 64; m++) {
+      const double ang = M_PI * (double)(m * (1 - 4 * b)) / (double)N;
+      t[TAB_TW0T + b * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
     }
 }
 
