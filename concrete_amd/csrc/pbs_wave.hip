@@ -306,12 +306,8 @@ __device__ __forceinline__ int32_t digit_of_rotated_difference(T rot, T own, uin
   if constexpr (sizeof(T) == 8 && BL <= 31) {
     const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int32_t)shifted, LOGN, 1);
     constexpr uint32_t HALF = 1u << (32 - BL - 1);
-#ifdef CAMD_NO_XAD
-    const uint32_t d = ((uint32_t)(rot >> 32) ^ m) + HALF;
-#else
     uint32_t d;   // (rot_hi ^ m) + HALF in one instruction; the compiler reassociates the sum and loses the pattern
     asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"((uint32_t)(rot >> 32)), "v"(m), "s"(HALF));
-#endif
     return (int32_t)(d - (uint32_t)(own >> 32)) >> (32 - BL);
   } else {
     const T r = ((shifted >> LOGN) & 1u) ? (T)(T(0) - rot) : rot;
@@ -1095,7 +1091,11 @@ constexpr int TAB_TWIST = 0;                 // [j] e^{+i pi j / N}, j < 256
 constexpr int TAB_A = 256;                   // [k-1][lane] W_256^(lane k), k = 1..3
 constexpr int TAB_B = TAB_A + 3 * 64;        // [k-1][m]    W_64^(m k),  m < 16
 constexpr int TAB_C = TAB_B + 3 * 16;        // [k-1][m]    W_16^(m k),  m < 4
-constexpr int TAB_COUNT = TAB_C + 3 * 4;
+constexpr int TAB_AT = TAB_C + 3 * 4;        // [k][lane] e^{i pi lane (1 - 4k) / N}, k = 0..3: TAB_A with the per-lane part of the twist folded in
+constexpr int TAB_COUNT = TAB_AT + 4 * 64;
+// the per-register part of the twist e^{i pi (64a + lane)/N} = e^{i pi a/8} e^{i pi lane/N}, a = 0..3
+constexpr double TWIST4_RE[4] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173};
+constexpr double TWIST4_IM[4] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
 constexpr int PLANE = 4 * 64;
 template <typename T, int K>
 constexpr size_t slab_bytes() { return (size_t)(K + 1) * N * sizeof(T) + 2 * PLANE * sizeof(double); }
@@ -1134,15 +1134,20 @@ __device__ __forceinline__ void exchange4(double2 (&x)[S][4], int lane, double* 
   }
 }
 
-template <int S>
+// FOLDED: the caller has applied only the per-register part of the twist (TWIST4_*); the per-lane
+// part commutes with the first radix-4 pass and comes with that pass's twiddles (TAB_AT), so no
+// twist table is read, for the same number of multiplications. The inverse mirrors it.
+template <int S, bool FOLDED = false>
 __device__ __forceinline__ void fft256_forward_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
                                                      double* sim) {
-  double2 w[3];
+  double2 w[3], w0;
+  if (FOLDED) w0 = tab[TAB_AT + lane];
 #pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_A + (k - 1) * 64 + lane];
+  for (int k = 1; k < 4; k++) w[k - 1] = FOLDED ? tab[TAB_AT + k * 64 + lane] : tab[TAB_A + (k - 1) * 64 + lane];
 #pragma unroll
   for (int s = 0; s < S; s++) {
     dft4<false>(x[s]);
+    if (FOLDED) x[s][0] = cmul(x[s][0], w0);
 #pragma unroll
     for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
   }
@@ -1169,10 +1174,10 @@ __device__ __forceinline__ void fft256_forward_multi(double2 (&x)[S][4], int lan
   for (int s = 0; s < S; s++) dft4<false>(x[s]);
 }
 
-template <int S>
+template <int S, bool FOLDED = false>
 __device__ __forceinline__ void fft256_inverse_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
                                                      double* sim) {
-  double2 w[3];
+  double2 w[3], w0;
 #pragma unroll
   for (int s = 0; s < S; s++) dft4<true>(x[s]);
   exchange4<S, 0>(x, lane, sre, sim);
@@ -1194,14 +1199,22 @@ __device__ __forceinline__ void fft256_inverse_multi(double2 (&x)[S][4], int lan
     dft4<true>(x[s]);
   }
   exchange4<S, 2>(x, lane, sre, sim);
+  if (FOLDED) w0 = tab[TAB_AT + lane];
 #pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_A + (k - 1) * 64 + lane];
+  for (int k = 1; k < 4; k++) w[k - 1] = FOLDED ? tab[TAB_AT + k * 64 + lane] : tab[TAB_A + (k - 1) * 64 + lane];
 #pragma unroll
   for (int s = 0; s < S; s++) {
+    if (FOLDED) x[s][0] = cmul_conj(x[s][0], w0);
 #pragma unroll
     for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
     dft4<true>(x[s]);
   }
+}
+__device__ __forceinline__ double2 twist4(double2 v, int a) {
+  return a == 0 ? v : cmul(v, make_double2(TWIST4_RE[a], TWIST4_IM[a]));
+}
+__device__ __forceinline__ double2 untwist4(double2 v, int a) {
+  return a == 0 ? v : cmul_conj(v, make_double2(TWIST4_RE[a], TWIST4_IM[a]));
 }
 
 // key conversion: one wave per polynomial, same transform, pre-scaled by 1/256
@@ -1305,11 +1318,10 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
             const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
             const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
             const T rot0 = p[s0 & (N - 1)], rot1 = p[s1 & (N - 1)];
-            const double2 tw = tab[TAB_TWIST + j0];
             if constexpr (L == 1) {
               const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, p[j0], s0);
               const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, p[j1], s1);
-              x[r][q] = cmul(make_double2((double)g0, (double)g1), tw);
+              x[r][q] = twist4(make_double2((double)g0, (double)g1), q);
             } else {
               const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
               const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
@@ -1318,7 +1330,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
               for (int l = L; l >= 1; l--) {
                 const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
-                x[(l - 1) * R + r][q] = cmul(make_double2((double)g0, (double)g1), tw);
+                x[(l - 1) * R + r][q] = twist4(make_double2((double)g0, (double)g1), q);
               }
             }
           }
@@ -1334,7 +1346,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
                          : "v"(lane_off), "s"(base), "n"(g * 1024 - 2048)
                          : "memory");
         }
-        fft256_forward_multi<S>(x, lane, tab, sre, sim);
+        fft256_forward_multi<S, true>(x, lane, tab, sre, sim);
       }
       double2 acc[R][4];
       if (!work) {
@@ -1389,14 +1401,14 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
           a_cur = wave_uniform(in[i]);
         }
       }
-      fft256_inverse_multi<R>(acc, lane, tab, sre, sim);
+      fft256_inverse_multi<R, true>(acc, lane, tab, sre, sim);
 #pragma unroll
       for (int c = 0; c < R; c++) {
         T* pc = ct0 + c * N;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const uint32_t j0 = 64 * q + lane;
-          const double2 v = cmul_conj(acc[c][q], tab[TAB_TWIST + j0]);
+          const double2 v = untwist4(acc[c][q], q);
           pc[j0] = torus_accumulate(pc[j0], v.x);
           pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
         }
@@ -1486,11 +1498,10 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
         const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
         const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
         const T rot0 = stage[s0 & (N - 1)], rot1 = stage[s1 & (N - 1)];
-        const double2 tw = tab[TAB_TWIST + j0];
         if constexpr (L == 1) {
           const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, acc[2 * q], s0);
           const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, acc[2 * q + 1], s1);
-          x[0][q] = cmul(make_double2((double)g0, (double)g1), tw);
+          x[0][q] = twist4(make_double2((double)g0, (double)g1), q);
         } else {
           const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
           const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
@@ -1499,11 +1510,11 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
 #pragma unroll
           for (int l = L; l >= 1; l--) {
             const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
-            x[l - 1][q] = cmul(make_double2((double)g0, (double)g1), tw);
+            x[l - 1][q] = twist4(make_double2((double)g0, (double)g1), q);
           }
         }
       }
-      fft256_forward_multi<L>(x, lane, tab, sre, sim);
+      fft256_forward_multi<L, true>(x, lane, tab, sre, sim);
 
       double2* img = spectra + (size_t)image * (S * M);
 #pragma unroll
@@ -1521,10 +1532,10 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
         for (int st = 1; st < S; st++) v = cfma(kk[st][g], img[(st * 4 + g) * 64 + lane], v);
         y[0][g] = v;
       }
-      fft256_inverse_multi<1>(y, lane, tab, sre, sim);
+      fft256_inverse_multi<1, true>(y, lane, tab, sre, sim);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const double2 v = cmul_conj(y[0][q], tab[TAB_TWIST + 64 * q + lane]);
+        const double2 v = untwist4(y[0][q], q);
         acc[2 * q] = torus_accumulate(acc[2 * q], v.x);
         acc[2 * q + 1] = torus_accumulate(acc[2 * q + 1], v.y);
       }
@@ -1570,6 +1581,11 @@ inline void fill_tables(double2* t) {
       t[TAB_C + (k - 1) * 4 + m] = make_double2(std::cos(ang), std::sin(ang));
     }
   }
+  for (int k = 0; k < 4; k++)
+    for (int m = 0; m < 64; m++) {
+      const double ang = M_PI * (double)(m * (1 - 4 * k)) / (double)N;
+      t[TAB_AT + k * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
 }
 
 template <typename T, int K, int L, int BL>
