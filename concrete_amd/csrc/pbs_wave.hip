@@ -120,12 +120,21 @@ __device__ __forceinline__ void dft8(double2 (&x)[8]) {
 
 // Forward transform of 512 points held as x[a] = point 64a + lane.
 // Result: x[g] = X[64 g + 8 (lane & 7) + (lane >> 3)].
+// FOLDED: `tab` is the bootstrap kernels' own image (TABV2_*): the caller has applied only the
+// per-register part of the twist and the per-lane part comes with the first pass's twiddles.
+template <bool FOLDED = false>
 __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const double2* tab, double* sre,
                                                double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
+  constexpr int TW1 = FOLDED ? TABV2_TW1 : TAB_TW1;
   dft8<false>(x);
+  if (FOLDED) {
 #pragma unroll
-  for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
+    for (int b = 0; b < 8; b++) x[b] = cmul(x[b], tab[TABV2_TW0T + b * 64 + lane]);
+  } else {
+#pragma unroll
+    for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
+  }
   // exchange 1: register index b <-> lane bits 5:3
 #pragma unroll
   for (int b = 0; b < 8; b++) {
@@ -138,7 +147,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
   }
   dft8<false>(x);
 #pragma unroll
-  for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW1 + (b - 1) * 8 + lo]);
+  for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TW1 + (b - 1) * 8 + lo]);
   // exchange 2: register index b' <-> lane bits 2:0 (XOR keeps both sides conflict-free)
 #pragma unroll
   for (int b = 0; b < 8; b++) {
@@ -154,9 +163,11 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
 }
 
 // Unnormalised inverse of fft512_forward: spectrum in, x[a] = 512 * point (64a + lane) out.
+template <bool FOLDED = false>
 __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const double2* tab, double* sre,
                                                double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
+  constexpr int TW1 = FOLDED ? TABV2_TW1 : TAB_TW1;
   dft8<true>(x);
 #pragma unroll
   for (int q = 0; q < 8; q++) {
@@ -169,7 +180,7 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
     x[b] = make_double2(sre[idx], sim[idx]);
   }
 #pragma unroll
-  for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW1 + (b - 1) * 8 + lo]);
+  for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TW1 + (b - 1) * 8 + lo]);
   dft8<true>(x);
 #pragma unroll
   for (int q = 0; q < 8; q++) {
@@ -178,9 +189,26 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
   }
 #pragma unroll
   for (int b = 0; b < 8; b++) x[b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
+  if (FOLDED) {
 #pragma unroll
-  for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
+    for (int b = 0; b < 8; b++) x[b] = cmul_conj(x[b], tab[TABV2_TW0T + b * 64 + lane]);
+  } else {
+#pragma unroll
+    for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
+  }
   dft8<true>(x);
+}
+// the per-register part of the twist and its inverse (a is a compile-time index at every call site)
+__device__ __forceinline__ double2 twist8(double2 v, int a) {
+  return a == 0 ? v : cmul(v, make_double2(TWIST8_RE[a], TWIST8_IM[a]));
+}
+__device__ __forceinline__ double2 untwist8(double2 v, int a) {
+  return a == 0 ? v : cmul_conj(v, make_double2(TWIST8_RE[a], TWIST8_IM[a]));
+}
+// the bootstrap kernels' LDS image of the tables: folded first-pass twiddles, second-pass twiddles
+__device__ __forceinline__ void stage_folded_tables(double2* tab, const double2* __restrict__ tables, int threads) {
+  for (int t = threadIdx.x; t < TABV2_COUNT; t += threads)
+    tab[t] = tables[t < TABV2_TW1 ? TAB_TW0T + t : TAB_TW1 + (t - TABV2_TW1)];
 }
 
 // f64 (torus units) -> torus word by magic-constant additions: with fr = t mod 1 in [0, 1), adding
@@ -329,10 +357,6 @@ constexpr size_t wave_slab_bytes() {
 }
 template <typename T, int K>
 constexpr size_t wave_lds_bytes() {
-  return TAB_COUNT * sizeof(double2) + WAVES * wave_slab_bytes<T, K>();
-}
-template <typename T, int K>
-constexpr size_t wave_v2_lds_bytes() {
   return TABV2_COUNT * sizeof(double2) + WAVES * wave_slab_bytes<T, K>();
 }
 
@@ -374,7 +398,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
   constexpr int N = 1024, M = 512, LOGN = 10;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = a.tables[t];
+  stage_folded_tables(tab, a.tables, 256);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -382,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
   const size_t ct = (size_t)blockIdx.x * WAVES + wave;
   if (ct >= a.count) return;
 
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
+  char* slab = smem + TABV2_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
   T* ct0 = (T*)slab;
   double* sre = (double*)(slab + (size_t)(K + 1) * N * sizeof(T));
   double* sim = sre + PLANE;
@@ -453,9 +477,9 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const int32_t g0 = digit_next32<BL, L>(st0[q]), g1 = digit_next32<BL, L>(st1[q]);
-          x[q] = cmul(make_double2((double)g0, (double)g1), tab[TAB_TWIST + 64 * q + lane]);
+          x[q] = twist8(make_double2((double)g0, (double)g1), q);
         }
-        fft512_forward(x, lane, tab, sre, sim);
+        fft512_forward<true>(x, lane, tab, sre, sim);
 #pragma unroll
         for (int c = 0; c <= K; c++) {
 #pragma unroll
@@ -490,12 +514,12 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
           z[g] = acc[c][g];
           acc[c][g] = make_double2(0.0, 0.0);
         }
-        fft512_inverse(z, lane, tab, sre, sim);
+        fft512_inverse<true>(z, lane, tab, sre, sim);
         T* pc = ct0 + c * N;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const uint32_t j0 = 64 * q + lane;
-          const double2 v = cmul_conj(z[q], tab[TAB_TWIST + j0]);
+          const double2 v = untwist8(z[q], q);
           pc[j0] = torus_accumulate(pc[j0], v.x);
           pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
         }
@@ -647,8 +671,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TABV2_COUNT; t += 256)
-    tab[t] = a.tables[t < TABV2_TW1 ? TAB_TW0T + t : TAB_TW1 + (t - TABV2_TW1)];
+  stage_folded_tables(tab, a.tables, 256);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -749,8 +772,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0[u & 1][t], own0[u & 1][t], j0 - a_hat);
           const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1[u & 1][t], own1[u & 1][t], j1 - a_hat);
           // the per-register part of the twist; the per-lane part is in the transform's twiddles
-          const double2 d = make_double2((double)g0, (double)g1);
-          x[u >> 1][q] = q == 0 ? d : cmul(d, make_double2(TWIST8_RE[q], TWIST8_IM[q]));
+          x[u >> 1][q] = twist8(make_double2((double)g0, (double)g1), q);
         }
       };
       issue(0);
@@ -878,7 +900,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           TorusSum prev0, prev1;
 #pragma unroll
           for (int q = 0; q < 8; q++) {
-            const double2 v = q == 0 ? acc[c][q] : cmul_conj(acc[c][q], make_double2(TWIST8_RE[q], TWIST8_IM[q]));
+            const double2 v = untwist8(acc[c][q], q);
             const TorusSum cur0 = torus_accumulate_begin(old0[c & 1][q], v.x);
             if (q > 0) pc[64 * (q - 1) + lane] = torus_accumulate_end(prev0);
             const TorusSum cur1 = torus_accumulate_begin(old1[c & 1][q], v.y);
@@ -893,7 +915,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
 #pragma unroll
           for (int q = 0; q < 8; q++) {
             const uint32_t j0 = 64 * q + lane;
-            const double2 v = q == 0 ? acc[c][q] : cmul_conj(acc[c][q], make_double2(TWIST8_RE[q], TWIST8_IM[q]));
+            const double2 v = untwist8(acc[c][q], q);
             pc[j0] = torus_accumulate(old0[c & 1][q], v.x);
             pc[j0 + M] = torus_accumulate(old1[c & 1][q], v.y);
           }
@@ -947,7 +969,7 @@ constexpr size_t lat_slab_bytes() {
 // Same products in the same order as the first one-wave schedule, hence the same ciphertext words.
 template <typename T, int K, int L>
 constexpr size_t wavelat_lds_bytes() {
-  return TAB_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T, K>() + 2 * (size_t)(K + 1) * L * 512 * sizeof(double2);
+  return TABV2_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T, K>() + 2 * (size_t)(K + 1) * L * 512 * sizeof(double2);
 }
 
 template <typename T, int K, int L, int BL>
@@ -955,16 +977,16 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
   constexpr int N = 1024, M = 512, LOGN = 10, R = K + 1, S = R * L, NS = S * R;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * R) tab[t] = a.tables[t];
+  stage_folded_tables(tab, a.tables, 64 * R);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = the polynomial this wave owns
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T, K>();
+  char* slab = smem + TABV2_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T, K>();
   double* sre = (double*)slab;
   double* sim = sre + PLANE;
   T* stage = (T*)(slab + 2 * PLANE * sizeof(double));
-  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T, K>());  // [2][S][8][64]
+  double2* spectra = (double2*)(smem + TABV2_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T, K>());  // [2][S][8][64]
   const uint32_t n = a.n;
   uint32_t image = 0;
 
@@ -1023,9 +1045,9 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const int32_t d0 = digit_next32<BL, L>(st0[q]), d1 = digit_next32<BL, L>(st1[q]);
-          x[q] = cmul(make_double2((double)d0, (double)d1), tab[TAB_TWIST + 64 * q + lane]);
+          x[q] = twist8(make_double2((double)d0, (double)d1), q);
         }
-        fft512_forward(x, lane, tab, sre, sim);
+        fft512_forward<true>(x, lane, tab, sre, sim);
 #pragma unroll
         for (int g = 0; g < 8; g++) img[(((l - 1) * R + wave) * 8 + g) * 64 + lane] = x[g];
       }
@@ -1046,10 +1068,10 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
           }
         x[g] = v;
       }
-      fft512_inverse(x, lane, tab, sre, sim);
+      fft512_inverse<true>(x, lane, tab, sre, sim);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
-        const double2 v = cmul_conj(x[q], tab[TAB_TWIST + 64 * q + lane]);
+        const double2 v = untwist8(x[q], q);
         acc[2 * q] = torus_accumulate(acc[2 * q], v.x);
         acc[2 * q + 1] = torus_accumulate(acc[2 * q + 1], v.y);
       }
@@ -1647,8 +1669,7 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
   if constexpr (L == 1) {
     if (schedule == 2) {
       auto kern2 = wave_pbs_kernel_v2<T, K, BL>;
-      constexpr size_t lds2 = wave_v2_lds_bytes<T, K>();
-      CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int dev = 0, cus = 0;
       CAMD_HIP(hipGetDevice(&dev));
       CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1657,7 +1678,7 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
         if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
         CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
       }
-      hipLaunchKernelGGL(kern2, dim3(persistent), dim3(256), lds2, stream, a);
+      hipLaunchKernelGGL(kern2, dim3(persistent), dim3(256), lds, stream, a);
       CAMD_HIP(hipGetLastError());
       return CAMD_OK;
     }
