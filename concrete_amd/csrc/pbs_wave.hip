@@ -1694,21 +1694,20 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
 
 size_t wave_scratch_bytes() { return 2 * (size_t)SYNC_GROUPS * SYNC_STRIDE * sizeof(uint32_t); }
 
-// the shortint instances (64-bit torus) are the default for their sets; the boolean one is opt-in
-bool wave_default(const camd_params& p) {
-  if (p.torus_bits != 64) return false;
-  if (p.polynomial_size == 1024) return p.glwe_dimension == 2 && p.pbs_level == 1 && p.pbs_base_log == 23;
-  return w4::supported(p);
-}
-
 // the boolean TFHE-lib parameters (32-bit torus, N = 1024, k = 1, three levels of base 2^7): first
-// schedule for large batches, the k+1-wave variant for small ones; on request, like the other
-// boolean instance
+// schedule for large batches, the k+1-wave variant for small ones
 static bool tfhe_lib_instance(const camd_params& p) {
   return p.torus_bits == 32 && p.polynomial_size == 1024 && p.glwe_dimension == 1 && p.pbs_level == 3 && p.pbs_base_log == 7;
 }
 
-bool wave_supported(const camd_params& p) { return wave_default(p) || w4::supported(p) || tfhe_lib_instance(p); }
+bool wave_supported(const camd_params& p) {
+  if (p.polynomial_size == 1024 && p.torus_bits == 64)
+    return p.glwe_dimension == 2 && p.pbs_level == 1 && p.pbs_base_log == 23;
+  return w4::supported(p) || tfhe_lib_instance(p);
+}
+
+// every set with an instance gets it by default; the bit-exact kernels stay selectable
+bool wave_default(const camd_params& p) { return wave_supported(p); }
 
 size_t wave_tables_count(uint32_t N) { return N == 512 ? (size_t)w4::TAB_COUNT : (size_t)TAB_TOTAL; }
 

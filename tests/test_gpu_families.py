@@ -95,11 +95,12 @@ def test_boolean_pbs_ks_bit_exact(gpu_ctx, params, variant):
 
 
 def test_full_size_boolean_nand_truth_table(gpu_ctx):
-    """BASELINE configs[0] on the GPU: NAND at DEFAULT_PARAMETERS with the full n = 586."""
+    """BASELINE configs[0] on the GPU: NAND at DEFAULT_PARAMETERS with the full n = 586, on the
+    bit-exact kernel (asked for explicitly; the default for this set is the wave kernel, next test but one)."""
     p = P.DEFAULT_PARAMETERS
     ks = get_keys(p, 32)
     o = ks.o
-    dk = device_key(gpu_ctx, ks, CAMD_PBS_AUTO)
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_BLOCK)
     acc = o.boolean_accumulator()
     dk.upload_lut(acc)
     T, F = 1 << 29, 7 << 29
@@ -218,14 +219,14 @@ def test_plain_c_caller(gpu_ctx, tmp_path):
 
 
 def test_boolean_wave_kernel_full_size(gpu_ctx):
-    """The wave-per-ciphertext instance for the boolean default parameters (asked for explicitly:
-    CAMD_PBS_AUTO keeps the bit-exact kernel for this set), full n = 586, against the oracle:
+    """The wave-per-ciphertext instance for the boolean default parameters (what CAMD_PBS_AUTO
+    selects for this set), full n = 586, against the oracle:
     every decryption identical, every gate of the truth table right, and ciphertext words within
     the last units of the 32-bit torus (same algorithm, different order of f64 operations)."""
     p = P.DEFAULT_PARAMETERS
     ks = get_keys(p, 32)
     o = ks.o
-    dk = device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_AUTO)
     assert dk.variant == CAMD_PBS_WAVE
     acc = o.boolean_accumulator()
     dk.upload_lut(acc)
@@ -268,7 +269,7 @@ def test_tfhe_lib_wave_kernel_full_size(gpu_ctx):
     p = P.TFHE_LIB_PARAMETERS
     ks = get_keys(p, 32)
     o = ks.o
-    dk = device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_AUTO)
     assert dk.variant == CAMD_PBS_WAVE
     acc = o.boolean_accumulator()
     dk.upload_lut(acc)
