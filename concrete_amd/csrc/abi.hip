@@ -183,8 +183,8 @@ int pick_variant(const camd_params& p, int requested, int* out) {
     return CAMD_OK;
   }
   if (requested != CAMD_PBS_AUTO) return fail(CAMD_EINVAL, "unknown pbs_variant");
-  // AUTO takes the wave kernel where it is the default (its results agree with the bit-exact
-  // families at the decryption level, not bit for bit); other wave instances are opt-in
+  // AUTO takes the wave kernel wherever it has an instance (its results agree with the bit-exact
+  // families at the decryption level, not bit for bit)
   *out = wave_default(p) ? CAMD_PBS_WAVE : block_supported(p) ? CAMD_PBS_BLOCK : CAMD_PBS_GENERIC;
   return CAMD_OK;
 }

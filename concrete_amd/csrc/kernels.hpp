@@ -126,8 +126,8 @@ int block_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables,
 template <typename T>
 int block_launch_pbs(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream);
 
-// ---- wave-per-ciphertext bootstrap: N = 1024 (64-bit, k = 2, one level) and N = 512 (32-bit, k = 2,
-// two levels) (pbs_wave.hip) ----
+// ---- wave-per-ciphertext bootstrap (pbs_wave.hip): N = 1024 (64-bit, k = 2, one level; 32-bit, k = 1,
+// three levels) and N = 512 (64-bit, k = 3, one level; 32-bit, k = 2, two levels) ----
 bool wave_supported(const camd_params& p);   // an instance exists (CAMD_PBS_WAVE may be requested)
 bool wave_default(const camd_params& p);     // ... and CAMD_PBS_AUTO selects it
 size_t wave_tables_count(uint32_t N);

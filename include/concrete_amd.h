@@ -61,9 +61,9 @@ typedef struct camd_params {
  * the CPU restatement of the reference algorithm; WAVE (one wavefront per ciphertext, the fastest
  * where it has an instance) performs the same algorithm with its own order of f64 operations:
  * decryptions and the noise bound are the same, the last bits of a ciphertext may differ. AUTO
- * picks WAVE for the shortint sets that have an instance (N = 1024 with k = 2, N = 512 with k = 3)
- * and BLOCK otherwise; the WAVE instances for the two boolean parameter sets (32-bit torus:
- * N = 512, k = 2, two levels; N = 1024, k = 1, three levels) are selected by asking for them.
+ * picks WAVE wherever it has an instance (shortint: N = 1024 with k = 2, N = 512 with k = 3; the two
+ * boolean parameter sets, 32-bit torus: N = 512, k = 2, two levels; N = 1024, k = 1, three levels)
+ * and BLOCK otherwise.
  * A WAVE batch of at most one ciphertext per CU (two for N = 512) runs on a variant that gives
  * each ciphertext k+1 wavefronts: less than half the latency, same decryptions; for the
  * shortint N = 1024 sets the words may differ from those the same ciphertext gets inside a
