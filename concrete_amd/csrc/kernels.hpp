@@ -131,6 +131,14 @@ int block_launch_pbs(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream);
 bool wave_supported(const camd_params& p);   // an instance exists (CAMD_PBS_WAVE may be requested)
 bool wave_default(const camd_params& p);     // ... and CAMD_PBS_AUTO selects it
 size_t wave_tables_count(uint32_t N);
+// the N = 512 instances (pbs_wave512.hip), reached through the wave_* functions
+bool wave512_supported(const camd_params& p);
+size_t wave512_tables_count();
+void wave512_fill_tables(double2* t);
+template <typename T>
+int wave512_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream);
+template <typename T>
+int wave512_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
 size_t wave_scratch_bytes();   // arrival counters of the persistent waves, cleared by every launch
 void wave_fill_tables(uint32_t N, double2* host_tables);
 template <typename T>

@@ -17,41 +17,38 @@
 //     the Fourier bootstrap key is stored in exactly the (register, lane) order the
 //     multiply-accumulate consumes, which makes every key load a coalesced 1 KiB access.
 //   * The 1/(N/2) of the inverse transform is folded into the key at conversion time.
-//   * f64 -> torus rounding uses two magic-constant additions instead of conversions.
-//   * Rows of the GGSW are consumed as soon as their transform is ready; the Fourier-domain
-//     sums for the k+1 output polynomials stay in registers.
-#include <cmath>
-#include <cstdlib>
-
-#include "kernels.hpp"
+//   * The twist of the negacyclic transform is split into eight constants and a per-lane factor
+//     that rides on the first pass's twiddles: no twist table is read.
+//   * f64 -> torus accumulation is four instructions (wave_common.hpp), the single-level digit of
+//     the rotated difference four more, on the high dwords only.
+//   * The default kernel (wave_pbs_kernel_v2, one decomposition level) runs the k+1 transforms of a
+//     CMUX interleaved and keeps the key rows of the next CMUX in accumulation registers; the
+//     first schedule (wave_pbs_kernel, any level count) and the k+1-waves-per-ciphertext variant
+//     for small batches (wave_pbs_kernel_lat) are in this file too. The N = 512 instances are in
+//     pbs_wave512.hip.
+#include "wave_common.hpp"
 
 namespace camd {
 
 namespace {
 
-constexpr int WAVES = 4;          // ciphertexts per workgroup
 constexpr int RADIX = 8;          // points per lane (N = 1024)
-constexpr int ROW = 72;           // padded row of the exchange image, in complex values (16 bytes)
-// The exchange image holds interleaved complex values and is accessed 16 bytes per lane: half
-// the LDS instructions of a planar image. The row padding and the XOR swizzle of the second
-// exchange keep every ds_read_b128 lane group (four non-contiguous groups of 16 lanes) and every
-// ds_write_b128 lane group (eight contiguous groups of 8) on distinct 16-byte bank units.
-#define XC(plane) ((double2*)(plane))
+constexpr int ROW = 72;           // padded row of an exchange plane, in doubles: every ds_write_b64 / ds_read_b64 lane group of both exchanges stays on distinct banks
 constexpr int PLANE = RADIX * ROW;
 
 // table layout, in double2 entries
 constexpr int TAB_TWIST = 0;                   // [a][lane]  e^{+i pi (64a+lane)/N}
 constexpr int TAB_TW0 = 512;                   // [b-1][lane] e^{-2 pi i lane b / 512}, b = 1..7
 constexpr int TAB_TW1 = TAB_TW0 + 7 * 64;      // [b-1][m]    e^{-2 pi i m b / 64},    b = 1..7, m < 8
-constexpr int TAB_COUNT = TAB_TW1 + 7 * 8;     // what the one-transform-at-a-time kernels stage in LDS
-// The interleaved-transform kernel splits the twist e^{i pi (64a+lane)/N} into a per-register part
+constexpr int TAB_COUNT = TAB_TW1 + 7 * 8;     // what the key-conversion kernel stages in LDS
+// The bootstrap kernels split the twist e^{i pi (64a+lane)/N} into a per-register part
 // e^{i pi a/16}, eight compile-time constants, and a per-lane part e^{i pi lane/N}. The per-lane part
 // commutes with the first radix-8 pass (it is the same for the eight inputs of a lane), so it is
 // folded into that pass's output twiddles: [b][lane] e^{i pi lane (1 - 4b)/N}, b = 0..7. No twist
 // table is read at all, for the same number of multiplications.
 constexpr int TAB_TW0T = TAB_COUNT;
 constexpr int TAB_TOTAL = TAB_TW0T + 8 * 64;
-constexpr int TABV2_TW0T = 0, TABV2_TW1 = 8 * 64, TABV2_COUNT = TABV2_TW1 + 7 * 8;   // that kernel's own LDS image
+constexpr int TABV2_TW0T = 0, TABV2_TW1 = 8 * 64, TABV2_COUNT = TABV2_TW1 + 7 * 8;   // their LDS image
 
 constexpr double HALF_SQRT2 = 0.70710678118654752440;
 // e^{i pi a / 16}, a = 0..7
@@ -61,21 +58,6 @@ constexpr double TWIST8_RE[8] = {1.0, 0.98078528040323044913, 0.9238795325112867
 constexpr double TWIST8_IM[8] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
                                  0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613,
                                  0.98078528040323044913};
-
-// Small batches go to the kernels that give a ciphertext k+1 waves: up to `fit` ciphertexts per
-// CU, where `fit` is the number of such workgroups a CU holds at once. CAMD_WAVE_LATENCY=0 keeps
-// the one-wave-per-ciphertext schedules for every batch size; a positive value replaces `fit`.
-inline size_t wave_latency_limit(int cus, int fit) {
-  static const int setting = []() {
-    const char* e = getenv("CAMD_WAVE_LATENCY");
-    return e ? atoi(e) : -1;
-  }();
-  if (setting == 0 || cus <= 0) return 0;
-  return (size_t)cus * (size_t)(setting > 0 ? setting : fit);
-}
-
-__device__ __forceinline__ double2 mul_neg_i(double2 v) { return make_double2(v.y, -v.x); }
-__device__ __forceinline__ double2 mul_pos_i(double2 v) { return make_double2(-v.y, v.x); }
 
 // 8-point DFT in registers, natural order in and out. INV selects e^{+2 pi i jk/8}.
 // The two odd eighth-roots (W8 and W8^3) scale by 1/sqrt(2); that factor is not applied where it
@@ -210,146 +192,6 @@ __device__ __forceinline__ void stage_folded_tables(double2* tab, const double2*
   for (int t = threadIdx.x; t < TABV2_COUNT; t += threads)
     tab[t] = tables[t < TABV2_TW1 ? TAB_TW0T + t : TAB_TW1 + (t - TABV2_TW1)];
 }
-
-// f64 (torus units) -> torus word by magic-constant additions: with fr = t mod 1 in [0, 1), adding
-// 1.5*2^20 leaves round(fr*2^32) in the low dword of the sum (a carry out of it is a whole turn of
-// the torus); the remainder, added to 1.5*2^-12, leaves round(rem*2^64) in its mantissa.
-template <typename T>
-__device__ __forceinline__ T from_torus_fast(double t);
-template <>
-__device__ __forceinline__ uint64_t from_torus_fast<uint64_t>(double t) {
-  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
-  const double a = fr + 0x1.8p20;
-  const uint32_t q = (uint32_t)__double2loint(a);
-  const double rem = fr - (a - 0x1.8p20);
-  const double b = rem + 0x1.8p-12;
-  const uint32_t lo = (uint32_t)__double2loint(b);
-  const uint32_t hi = q + (uint32_t)((__double2hiint(b) & 0xFFFFF) - 0x80000);
-  return ((uint64_t)hi << 32) | lo;
-}
-// acc += t (torus units) rounded to 52 fractional bits, in four instructions. With fr = t mod 1,
-// b = 1 + fr has the exponent of 1.0, or is exactly 2.0, so its mantissa m is fr in units of 2^-52
-// (zero for b = 2.0: a whole turn) and the addend is m << 12: the low dword of b times 2^12 goes in
-// as a 32 x 32 + 64 bit multiply-add, the 20 mantissa bits of the high dword are shifted to the top
-// of the high dword, where the exponent bits fall off. The 12 bits this drops are 2^-52 of the
-// torus, five orders of magnitude below what the f64 transforms themselves leave in a coefficient.
-// The two instructions are written out: the compiler rebuilds the shift from the 64-bit pattern in
-// three instructions and has no pattern for a multiply-add by a power of two. They are separate
-// calls because v_mad_u64_u32 costs an idle slot when it reads a register written by the
-// instruction before it: a caller with several sums in flight does all the first halves first.
-struct TorusSum {
-  uint64_t partial;   // acc with the top 20 mantissa bits added into the high dword
-  uint32_t low;       // low dword of b = 1 + (t mod 1)
-};
-__device__ __forceinline__ TorusSum torus_accumulate_begin(uint64_t acc, double t) {
-  const double b = __builtin_amdgcn_fract(t) + 1.0;
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  u32x2 w = __builtin_bit_cast(u32x2, acc);
-  asm("v_lshl_add_u32 %0, %1, 12, %0" : "+v"(w.y) : "v"(__double2hiint(b)));
-  TorusSum s;
-  s.partial = __builtin_bit_cast(uint64_t, w);
-  s.low = (uint32_t)__double2loint(b);
-  return s;
-}
-__device__ __forceinline__ uint64_t torus_accumulate_end(const TorusSum& s) {
-  uint64_t r;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(s.low), "s"(4096u), "v"(s.partial) : "vcc");
-  return r;
-}
-__device__ __forceinline__ uint64_t torus_accumulate(uint64_t acc, double t) {
-  return torus_accumulate_end(torus_accumulate_begin(acc, t));
-}
-__device__ __forceinline__ uint32_t torus_accumulate(uint32_t acc, double t) {
-  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
-  return acc + (uint32_t)__double2loint(fr + 0x1.8p20);
-}
-template <>
-__device__ __forceinline__ uint32_t from_torus_fast<uint32_t>(double t) {
-  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
-  return (uint32_t)__double2loint(fr + 0x1.8p20);
-}
-
-// Decomposition state in 32 bits. Only the top BL*L bits of the word (plus the rounding bit
-// below them) enter the digits; when those lie in the high dword the 64-bit shifts of the
-// generic form are not needed. The result equals decomp_init_state() for every input.
-template <typename T, int BL, int L>
-__device__ __forceinline__ uint32_t digit_state32(T x) {
-  constexpr int BITS = Torus<T>::BITS;
-  constexpr int NON_REP = BITS - BL * L;
-  static_assert(BL * L <= 31, "decomposition wider than 31 bits");
-  if constexpr (BITS == 64 && NON_REP >= 33) {
-    const uint32_t hi = (uint32_t)(x >> 32);
-    // (hi >> s) + rounding bit == (hi + 2^(s-1)) >> s up to a carry out of bit 31, which the
-    // mask would drop anyway
-    constexpr int S = NON_REP - 32;
-    return ((hi + (1u << (S - 1))) >> S) & ((1u << (BL * L)) - 1u);
-  } else {
-    return (uint32_t)decomp_init_state<T>(x, BL, L);
-  }
-}
-// next signed digit (level L first); same recurrence as decompose_one_level, in 32 bits
-template <int BL, int L>
-__device__ __forceinline__ int32_t digit_next32(uint32_t& state) {
-  if constexpr (L == 1) {
-    // single level: state already holds BL bits; carry = (res > B/2)
-    const uint32_t res = state;
-    return (int32_t)res - ((res > (1u << (BL - 1))) ? (1 << BL) : 0);
-  } else {
-    return (int32_t)decomp_next<uint32_t>(state, BL);
-  }
-}
-
-// Single-level decomposition in one go: the signed digit of x. With state = the top BL bits of x
-// rounded to nearest, the digit is state for state <= B/2 and state - B above. Both the rounding
-// and the fold are additions below the extracted field, so they merge into one constant:
-//   ((hi + 2^(S-1) + (C << S)) >> S) mod B  ==  (state + C) mod B,   C = B/2 - 1,
-// and (state + C) mod B - C is state for state <= B/2 (no wrap) and state - B above (one wrap).
-// Three integer instructions and no condition register, against six and a compare.
-template <typename T, int BL>
-__device__ __forceinline__ int32_t digit_single32(T x) {
-  constexpr int BITS = Torus<T>::BITS;
-  constexpr int NON_REP = BITS - BL;
-  if constexpr (BITS == 64 && NON_REP >= 33) {
-    constexpr int S = NON_REP - 32;
-    constexpr uint32_t C = (1u << (BL - 1)) - 1u;
-    const uint32_t hi = (uint32_t)(x >> 32);
-    const uint32_t w = __builtin_amdgcn_ubfe(hi + ((1u << (S - 1)) + (C << S)), S, BL);
-    return (int32_t)w - (int32_t)C;
-  } else {
-    uint32_t st = digit_state32<T, BL, 1>(x);
-    return digit_next32<BL, 1>(st);
-  }
-}
-
-// Signed single-level digit of (wrapped ? -rot : rot) - own, where `shifted` = j - a_hat carries the
-// wrap in bit LOGN. For a 64-bit torus whose digit lies in the high dword only the high dwords
-// enter: the difference has the high dword (rot_hi ^ m) - own_hi with m = 0 or all ones, up to the
-// borrow of the low halves (and the +1 of a negation whose low dword is zero). The digit is that
-// value rounded at bit 32 - BL, so leaving the borrow out moves the value being rounded by at most
-// 2^-32 of the torus against a rounding step of 2^-BL: the decomposition error bound B^-1/2 grows
-// by a factor 1 + 2^(BL-31). The rounding is an arithmetic shift: digits in [-B/2, B/2) where the
-// generic form has (-B/2, B/2]; the two ends are the same residue.
-template <typename T, int BL, int LOGN>
-__device__ __forceinline__ int32_t digit_of_rotated_difference(T rot, T own, uint32_t shifted) {
-  if constexpr (sizeof(T) == 8 && BL <= 31) {
-    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int32_t)shifted, LOGN, 1);
-    constexpr uint32_t HALF = 1u << (32 - BL - 1);
-    uint32_t d;   // (rot_hi ^ m) + HALF in one instruction; the compiler reassociates the sum and loses the pattern
-    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"((uint32_t)(rot >> 32)), "v"(m), "s"(HALF));
-    return (int32_t)(d - (uint32_t)(own >> 32)) >> (32 - BL);
-  } else {
-    const T r = ((shifted >> LOGN) & 1u) ? (T)(T(0) - rot) : rot;
-    return digit_single32<T, BL>((T)(r - own));
-  }
-}
-
-// broadcast lane 0's value through SGPRs so that the compiler sees a wave-uniform value
-__device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <typename T, int K>
 constexpr size_t wave_slab_bytes() {
@@ -541,11 +383,6 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
   if (lane == 0) out[K * N] = ct0[K * N];
 }
 
-
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double2 as_double2(v4u v) {
-  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
-}
 
 // ---- interleaved transforms: S independent polynomials advance through the passes together ----
 // One wave, one exchange image: LDS operations of a wave execute in order, so the write/read
@@ -1092,554 +929,6 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
   }
 }
 
-// ================================================================================================
-// N = 512 instance (the boolean default parameters: 32-bit torus, k = 2, two levels, base 2^8).
-// Same schedule as wave_pbs_kernel_v2 — one wave per ciphertext, the transforms of a CMUX
-// interleaved as independent streams, the key rows of the next CMUX parked in accumulation
-// registers — with four points per lane: a 256-point transform is four radix-4 passes with three
-// exchanges, each a 4 x 4 transpose between the register index and one base-4 digit of the lane
-// index. With n = 64 a + lane, lane = 16 l2 + 4 l1 + l0 and f = k1 + 4 k2 + 16 k3 + 64 k4:
-//   pass 1 over a  (twiddle W_256^(lane k1)),      exchange register <-> l2,
-//   pass 2 over l2 (twiddle W_64^((lane & 15) k2)), exchange register <-> l1,
-//   pass 3 over l1 (twiddle W_16^((lane & 3) k3)),  exchange register <-> l0,
-//   pass 4 over l0; register k4 of lane 16 k1 + 4 k2 + k3 then holds X[f].
-// The inverse runs the mirror image (conjugate twiddles, same exchanges), unnormalised; the key
-// is pre-multiplied by 1/256. The exchange image is 4 rows of 64 values per plane, element
-// (r, lane) at r * 64 + (lane ^ (r << 2 * digit)): conflict-free for the lane groups of
-// ds_write_b64 and ds_read_b64 on both sides of every exchange (checked by enumeration).
-namespace w4 {
-constexpr int N = 512, M = 256, LOGN = 9;
-constexpr int TAB_TWIST = 0;                 // [j] e^{+i pi j / N}, j < 256
-constexpr int TAB_A = 256;                   // [k-1][lane] W_256^(lane k), k = 1..3
-constexpr int TAB_B = TAB_A + 3 * 64;        // [k-1][m]    W_64^(m k),  m < 16
-constexpr int TAB_C = TAB_B + 3 * 16;        // [k-1][m]    W_16^(m k),  m < 4
-constexpr int TAB_AT = TAB_C + 3 * 4;        // [k][lane] e^{i pi lane (1 - 4k) / N}, k = 0..3: TAB_A with the per-lane part of the twist folded in
-constexpr int TAB_COUNT = TAB_AT + 4 * 64;
-// the per-register part of the twist e^{i pi (64a + lane)/N} = e^{i pi a/8} e^{i pi lane/N}, a = 0..3
-constexpr double TWIST4_RE[4] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173};
-constexpr double TWIST4_IM[4] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
-constexpr int PLANE = 4 * 64;
-template <typename T, int K>
-constexpr size_t slab_bytes() { return (size_t)(K + 1) * N * sizeof(T) + 2 * PLANE * sizeof(double); }
-template <typename T, int K>
-constexpr size_t lds_bytes() { return TAB_COUNT * sizeof(double2) + WAVES * slab_bytes<T, K>(); }
-
-template <bool INV>
-__device__ __forceinline__ void dft4(double2 (&x)[4]) {
-  const double2 s0 = cadd(x[0], x[2]), d0 = csub(x[0], x[2]);
-  const double2 s1 = cadd(x[1], x[3]), d1 = csub(x[1], x[3]);
-  const double2 t = INV ? mul_pos_i(d1) : mul_neg_i(d1);
-  x[0] = cadd(s0, s1);
-  x[2] = csub(s0, s1);
-  x[1] = cadd(d0, t);
-  x[3] = csub(d0, t);
-}
-
-// transpose between the register index and base-4 digit DIGIT of the lane index, all streams
-template <int S, int DIGIT>
-__device__ __forceinline__ void exchange4(double2 (&x)[S][4], int lane, double* sre, double* sim) {
-  constexpr int SH = 2 * DIGIT;
-  const int d = (lane >> SH) & 3;
-  const int rest = lane & ~(3 << SH);
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int pos = r * 64 + (lane ^ (r << SH));
-      sre[pos] = x[s][r].x; sim[pos] = x[s][r].y;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int idx = d * 64 + (rest | ((j ^ d) << SH));
-      x[s][j] = make_double2(sre[idx], sim[idx]);
-    }
-  }
-}
-
-// FOLDED: the caller has applied only the per-register part of the twist (TWIST4_*); the per-lane
-// part commutes with the first radix-4 pass and comes with that pass's twiddles (TAB_AT), so no
-// twist table is read, for the same number of multiplications. The inverse mirrors it.
-template <int S, bool FOLDED = false>
-__device__ __forceinline__ void fft256_forward_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
-                                                     double* sim) {
-  double2 w[3], w0;
-  if (FOLDED) w0 = tab[TAB_AT + lane];
-#pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = FOLDED ? tab[TAB_AT + k * 64 + lane] : tab[TAB_A + (k - 1) * 64 + lane];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-    dft4<false>(x[s]);
-    if (FOLDED) x[s][0] = cmul(x[s][0], w0);
-#pragma unroll
-    for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
-  }
-  exchange4<S, 2>(x, lane, sre, sim);
-#pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_B + (k - 1) * 16 + (lane & 15)];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-    dft4<false>(x[s]);
-#pragma unroll
-    for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
-  }
-  exchange4<S, 1>(x, lane, sre, sim);
-#pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_C + (k - 1) * 4 + (lane & 3)];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-    dft4<false>(x[s]);
-#pragma unroll
-    for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
-  }
-  exchange4<S, 0>(x, lane, sre, sim);
-#pragma unroll
-  for (int s = 0; s < S; s++) dft4<false>(x[s]);
-}
-
-template <int S, bool FOLDED = false>
-__device__ __forceinline__ void fft256_inverse_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
-                                                     double* sim) {
-  double2 w[3], w0;
-#pragma unroll
-  for (int s = 0; s < S; s++) dft4<true>(x[s]);
-  exchange4<S, 0>(x, lane, sre, sim);
-#pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_C + (k - 1) * 4 + (lane & 3)];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-#pragma unroll
-    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
-    dft4<true>(x[s]);
-  }
-  exchange4<S, 1>(x, lane, sre, sim);
-#pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_B + (k - 1) * 16 + (lane & 15)];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-#pragma unroll
-    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
-    dft4<true>(x[s]);
-  }
-  exchange4<S, 2>(x, lane, sre, sim);
-  if (FOLDED) w0 = tab[TAB_AT + lane];
-#pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = FOLDED ? tab[TAB_AT + k * 64 + lane] : tab[TAB_A + (k - 1) * 64 + lane];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-    if (FOLDED) x[s][0] = cmul_conj(x[s][0], w0);
-#pragma unroll
-    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
-    dft4<true>(x[s]);
-  }
-}
-__device__ __forceinline__ double2 twist4(double2 v, int a) {
-  return a == 0 ? v : cmul(v, make_double2(TWIST4_RE[a], TWIST4_IM[a]));
-}
-__device__ __forceinline__ double2 untwist4(double2 v, int a) {
-  return a == 0 ? v : cmul_conj(v, make_double2(TWIST4_RE[a], TWIST4_IM[a]));
-}
-
-// key conversion: one wave per polynomial, same transform, pre-scaled by 1/256
-template <typename T>
-__global__ __launch_bounds__(256) void bsk_fourier_kernel(const T* __restrict__ bsk, double2* __restrict__ out,
-                                                          const double2* __restrict__ tables, size_t polys) {
-  extern __shared__ __align__(16) char smem[];
-  double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = tables[t];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* sre = (double*)(smem + TAB_COUNT * sizeof(double2)) + (size_t)wave * 2 * PLANE;
-  double* sim = sre + PLANE;
-  const size_t poly = (size_t)blockIdx.x * WAVES + wave;
-  if (poly >= polys) return;
-  using SG = typename Torus<T>::Signed;
-  constexpr double SCALE = (sizeof(T) == 8 ? 0x1.0p-64 : 0x1.0p-32) / 256.0;
-  const T* p = bsk + poly * N;
-  double2 x[1][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++) {
-    const int j = 64 * a + lane;
-    const double re = signed_to_double((SG)p[j]) * SCALE;
-    const double im = signed_to_double((SG)p[j + M]) * SCALE;
-    x[0][a] = cmul(make_double2(re, im), tab[TAB_TWIST + j]);
-  }
-  fft256_forward_multi<1>(x, lane, tab, sre, sim);
-  double2* dst = out + poly * M;
-#pragma unroll
-  for (int g = 0; g < 4; g++) dst[g * 64 + lane] = x[0][g];
-}
-
-template <int BL>
-__device__ __forceinline__ int32_t next_digit(uint32_t& state) {
-  const uint32_t res = state & ((1u << BL) - 1u);
-  state >>= BL;
-  uint32_t carry = ((res - 1u) | state) & res;
-  carry >>= (BL - 1);
-  state += carry;
-  return (int32_t)(res - (carry << BL));
-}
-
-template <typename T, int K, int L, int BL>
-__global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
-  constexpr int R = K + 1;
-  extern __shared__ __align__(16) char smem[];
-  double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = a.tables[t];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * slab_bytes<T, K>();
-  T* ct0 = (T*)slab;
-  double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
-  double* sim = sre + PLANE;
-  constexpr int S = R * L;          // forward streams: (level - 1) * R + row
-  constexpr int NS = S * R;         // key slabs per iteration: [level][row][col], 4 KiB each
-  constexpr int NA = NS < 14 ? NS : 14;   // slabs parked in accumulation registers (at most 224 AGPRs)
-  const uint32_t lane_off = (uint32_t)lane * 16u;
-  // persistent waves restart together per XCD (see wave_pbs_kernel_v2): key rows are then fetched
-  // into each L2 once instead of once per drifting wave
-  XcdRendezvous rendezvous;
-  if (a.scratch) rendezvous.enrol(a.scratch, lane);
-  const size_t per_round = (size_t)gridDim.x * WAVES;
-  uint32_t round = 0;
-  for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round, round++) {
-    const T* in = a.ct_in + ct * a.in_stride;
-    const uint32_t n = a.n;
-    const uint32_t lut_id = checked_lut_id(a, ct);
-    const T* lut = a.luts + (size_t)lut_id * (R * N);
-    {
-      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
-      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
-      for (int idx = lane; idx < R * N; idx += 64) {
-        const int c = idx >> LOGN, j = idx & (N - 1);
-        ct0[idx] = rotated_coeff<T>(lut + (size_t)c * N, j, d0, N);
-      }
-    }
-    uint32_t i = 0;
-    T a_cur = wave_uniform(in[0]);
-    while (i < n && a_cur == 0) {
-      i++;
-      a_cur = wave_uniform(in[i]);
-    }
-    v4u bqa[NA][4];
-#pragma unroll
-    for (int sl = 0; sl < NA; sl++)
-#pragma unroll
-      for (int g = 0; g < 4; g++) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(bqa[sl][g].x));
-    bool work = false;
-    uint32_t a_hat = 0, cur = 0;
-    for (;;) {
-      double2 x[S][4];
-      v4u bqv[NS - NA > 0 ? NS - NA : 1][4];
-      if (work) {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          const T* p = ct0 + r * N;
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-            const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
-            const T rot0 = p[s0 & (N - 1)], rot1 = p[s1 & (N - 1)];
-            if constexpr (L == 1) {
-              const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, p[j0], s0);
-              const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, p[j1], s1);
-              x[r][q] = twist4(make_double2((double)g0, (double)g1), q);
-            } else {
-              const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
-              const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
-              uint32_t st0 = digit_state32<T, BL, L>((T)(r0 - p[j0]));
-              uint32_t st1 = digit_state32<T, BL, L>((T)(r1 - p[j1]));
-#pragma unroll
-              for (int l = L; l >= 1; l--) {
-                const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
-                x[(l - 1) * R + r][q] = twist4(make_double2((double)g0, (double)g1), q);
-              }
-            }
-          }
-        }
-        // the slabs that do not fit the accumulation registers: requested now, needed after the transforms
-#pragma unroll
-        for (int sl = NA; sl < NS; sl++) {
-          const char* base = (const char*)(a.fbsk + (size_t)cur * NS * M) + (size_t)sl * (M * sizeof(double2)) + 2048;
-#pragma unroll
-          for (int g = 0; g < 4; g++)
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-                         : "=v"(bqv[sl - NA][g])
-                         : "v"(lane_off), "s"(base), "n"(g * 1024 - 2048)
-                         : "memory");
-        }
-        fft256_forward_multi<S, true>(x, lane, tab, sre, sim);
-      }
-      double2 acc[R][4];
-      if (!work) {
-#pragma unroll
-        for (int c = 0; c < R; c++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) acc[c][g] = make_double2(0.0, 0.0);
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int sl = 0; sl < NA; sl++)
-          asm volatile("" : "+a"(bqa[sl][0]), "+a"(bqa[sl][1]), "+a"(bqa[sl][2]), "+a"(bqa[sl][3]));
-#pragma unroll
-        for (int sl = NA; sl < NS; sl++)
-          asm volatile("" : "+v"(bqv[sl - NA][0]), "+v"(bqv[sl - NA][1]), "+v"(bqv[sl - NA][2]), "+v"(bqv[sl - NA][3]));
-        auto key = [&](int s, int c, int g) -> double2 {
-          const int sl = s * R + c;
-          return as_double2(sl < NA ? bqa[sl < NA ? sl : 0][g] : bqv[sl >= NA ? sl - NA : 0][g]);
-        };
-#pragma unroll
-        for (int c = 0; c < R; c++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) {
-            double2 v = cmul(key(0, c, g), x[0][g]);
-#pragma unroll
-            for (int s = 1; s < S; s++) v = cfma(key(s, c, g), x[s][g], v);
-            acc[c][g] = v;
-          }
-      }
-      // key rows of the next active iteration (index i), if any
-      const bool more = i < n;
-      const char* ggsw = (const char*)(a.fbsk + (size_t)(more ? i : 0) * NS * M);
-      if (more) {
-#pragma unroll
-        for (int sl = 0; sl < NA; sl++) {
-          const char* base = ggsw + (size_t)sl * (M * sizeof(double2)) + 2048;
-#pragma unroll
-          for (int g = 0; g < 4; g++)
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-                         : "=a"(bqa[sl][g])
-                         : "v"(lane_off), "s"(base), "n"(g * 1024 - 2048)
-                         : "memory");
-        }
-      }
-      const uint32_t next_i = i;
-      const uint32_t next_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
-      if (more) {
-        i++;
-        a_cur = wave_uniform(in[i]);
-        while (i < n && a_cur == 0) {
-          i++;
-          a_cur = wave_uniform(in[i]);
-        }
-      }
-      fft256_inverse_multi<R, true>(acc, lane, tab, sre, sim);
-#pragma unroll
-      for (int c = 0; c < R; c++) {
-        T* pc = ct0 + c * N;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint32_t j0 = 64 * q + lane;
-          const double2 v = untwist4(acc[c][q], q);
-          pc[j0] = torus_accumulate(pc[j0], v.x);
-          pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
-        }
-      }
-      if (!more) break;
-      work = true;
-      a_hat = next_hat;
-      cur = next_i;
-    }
-    T* out = a.ct_out + ct * a.out_stride;
-    for (int idx = lane; idx < K * N; idx += 64) {
-      const int c = idx >> LOGN, j = idx & (N - 1);
-      const T* p = ct0 + c * N;
-      out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
-    }
-    if (lane == 0) out[K * N] = ct0[K * N];
-    if ((size_t)(round + 1) * per_round < a.count) rendezvous.arrive_and_wait(round, lane);
-  }
-}
-
-// Latency variant (see wave_pbs_kernel_lat): k+1 waves per ciphertext, wave c owning polynomial
-// c. It transforms the L digit polynomials of its own polynomial, publishes them, and after the
-// barrier accumulates column c over all (k+1) L spectra in the order of pbs_kernel, so both give
-// the same ciphertext words.
-template <typename T>
-constexpr size_t lat_slab_bytes() { return (size_t)N * sizeof(T) + 2 * PLANE * sizeof(double); }
-template <typename T, int K, int L>
-constexpr size_t lat_lds_bytes() {
-  return TAB_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T>() + 2 * (size_t)(K + 1) * L * M * sizeof(double2);
-}
-
-template <typename T, int K, int L, int BL>
-__global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
-  constexpr int R = K + 1, S = R * L, NS = S * R;
-  extern __shared__ __align__(16) char smem[];
-  double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * R) tab[t] = a.tables[t];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = the polynomial this wave owns
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T>();
-  T* stage = (T*)slab;
-  double* sre = (double*)(slab + (size_t)N * sizeof(T));
-  double* sim = sre + PLANE;
-  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T>());  // [2][S][4][64]
-  const uint32_t n = a.n;
-  uint32_t image = 0;
-
-  for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
-    const T* in = a.ct_in + ct * a.in_stride;
-    const uint32_t lut_id = checked_lut_id(a, ct);
-    const T* lut = a.luts + (size_t)lut_id * (R * N) + (size_t)wave * N;
-    // acc[2q] = coefficient 64q + lane, acc[2q+1] = coefficient 64q + lane + N/2 of the own polynomial
-    T acc[8];
-    {
-      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
-      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        acc[2 * q] = rotated_coeff<T>(lut, 64 * q + lane, d0, N);
-        acc[2 * q + 1] = rotated_coeff<T>(lut, 64 * q + lane + M, d0, N);
-      }
-    }
-    T a_next = wave_uniform(in[0]);
-    for (uint32_t i = 0; i < n; i++) {
-      const T a_cur = a_next;
-      a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
-      if (a_cur == 0) continue;           // skipped by every wave of the group alike
-      const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
-
-      // column `wave` of key row i, every stream
-      const double2* key = a.fbsk + (size_t)i * NS * M + (size_t)wave * M + lane;
-      double2 kk[S][4];
-#pragma unroll
-      for (int st = 0; st < S; st++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) kk[st][g] = key[(size_t)(st * R) * M + g * 64];
-
-      double2 x[L][4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        stage[64 * q + lane] = acc[2 * q];
-        stage[64 * q + lane + M] = acc[2 * q + 1];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-        const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
-        const T rot0 = stage[s0 & (N - 1)], rot1 = stage[s1 & (N - 1)];
-        if constexpr (L == 1) {
-          const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, acc[2 * q], s0);
-          const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, acc[2 * q + 1], s1);
-          x[0][q] = twist4(make_double2((double)g0, (double)g1), q);
-        } else {
-          const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
-          const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
-          uint32_t st0 = digit_state32<T, BL, L>((T)(r0 - acc[2 * q]));
-          uint32_t st1 = digit_state32<T, BL, L>((T)(r1 - acc[2 * q + 1]));
-#pragma unroll
-          for (int l = L; l >= 1; l--) {
-            const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
-            x[l - 1][q] = twist4(make_double2((double)g0, (double)g1), q);
-          }
-        }
-      }
-      fft256_forward_multi<L, true>(x, lane, tab, sre, sim);
-
-      double2* img = spectra + (size_t)image * (S * M);
-#pragma unroll
-      for (int l = 0; l < L; l++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) img[((l * R + wave) * 4 + g) * 64 + lane] = x[l][g];
-      __syncthreads();
-      image ^= 1u;
-
-      double2 y[1][4];
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        double2 v = cmul(kk[0][g], img[(0 * 4 + g) * 64 + lane]);
-#pragma unroll
-        for (int st = 1; st < S; st++) v = cfma(kk[st][g], img[(st * 4 + g) * 64 + lane], v);
-        y[0][g] = v;
-      }
-      fft256_inverse_multi<1, true>(y, lane, tab, sre, sim);
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const double2 v = untwist4(y[0][q], q);
-        acc[2 * q] = torus_accumulate(acc[2 * q], v.x);
-        acc[2 * q + 1] = torus_accumulate(acc[2 * q + 1], v.y);
-      }
-    }
-
-    // sample extraction of coefficient 0: out[c N + (N - j) mod N] = (j == 0) ? p[j] : -p[j]
-    T* out = a.ct_out + ct * a.out_stride;
-    if (wave < K) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-        out[(size_t)wave * N + ((N - j0) & (N - 1))] = (j0 == 0) ? acc[2 * q] : (T)(T(0) - acc[2 * q]);
-        out[(size_t)wave * N + (N - j1)] = (T)(T(0) - acc[2 * q + 1]);
-      }
-    } else if (lane == 0) {
-      out[K * N] = acc[0];
-    }
-  }
-}
-
-inline bool supported(const camd_params& p) {
-  if (p.polynomial_size != 512) return false;
-  if (p.torus_bits == 32) return p.glwe_dimension == 2 && p.pbs_level == 2 && p.pbs_base_log == 8;
-  return p.glwe_dimension == 3 && p.pbs_level == 1 && p.pbs_base_log == 18;   // the three small shortint sets
-}
-
-inline void fill_tables(double2* t) {
-  for (int j = 0; j < 256; j++) {
-    const double ang = M_PI * (double)j / (double)N;
-    t[TAB_TWIST + j] = make_double2(std::cos(ang), std::sin(ang));
-  }
-  for (int k = 1; k < 4; k++) {
-    for (int m = 0; m < 64; m++) {
-      const double ang = -2.0 * M_PI * (double)(m * k) / 256.0;
-      t[TAB_A + (k - 1) * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
-    }
-    for (int m = 0; m < 16; m++) {
-      const double ang = -2.0 * M_PI * (double)(m * k) / 64.0;
-      t[TAB_B + (k - 1) * 16 + m] = make_double2(std::cos(ang), std::sin(ang));
-    }
-    for (int m = 0; m < 4; m++) {
-      const double ang = -2.0 * M_PI * (double)(m * k) / 16.0;
-      t[TAB_C + (k - 1) * 4 + m] = make_double2(std::cos(ang), std::sin(ang));
-    }
-  }
-  for (int k = 0; k < 4; k++)
-    for (int m = 0; m < 64; m++) {
-      const double ang = M_PI * (double)(m * (1 - 4 * k)) / (double)N;
-      t[TAB_AT + k * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
-    }
-}
-
-template <typename T, int K, int L, int BL>
-int launch(const PbsLaunch<T>& a, hipStream_t stream) {
-  constexpr size_t lds = lds_bytes<T, K>();
-  static_assert(lds <= 160 * 1024, "LDS budget exceeded");
-  auto kern = pbs_kernel<T, K, L, BL>;
-  if (lds > 64 * 1024) CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int dev = 0, cus = 0;
-  CAMD_HIP(hipGetDevice(&dev));
-  CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  constexpr int lat_fit = (int)((160 * 1024) / lat_lds_bytes<T, K, L>());
-  if (a.count <= wave_latency_limit(cus, lat_fit)) {
-    constexpr size_t ldsl = lat_lds_bytes<T, K, L>();
-    static_assert(ldsl <= 160 * 1024, "LDS budget exceeded");
-    auto kernl = pbs_kernel_lat<T, K, L, BL>;
-    if (ldsl > 64 * 1024) CAMD_HIP(hipFuncSetAttribute((const void*)kernl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl));
-    hipLaunchKernelGGL(kernl, dim3((unsigned)a.count), dim3(64 * (K + 1)), ldsl, stream, a);
-    CAMD_HIP(hipGetLastError());
-    return CAMD_OK;
-  }
-  const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
-  const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // one wave per SIMD (512 registers)
-  if (persistent < grid) {
-    if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
-    CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
-  }
-  hipLaunchKernelGGL(kern, dim3(persistent), dim3(256), lds, stream, a);
-  CAMD_HIP(hipGetLastError());
-  return CAMD_OK;
-}
-}  // namespace w4
 
 template <typename T, int K, int L, int BL>
 int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
@@ -1703,17 +992,17 @@ static bool tfhe_lib_instance(const camd_params& p) {
 bool wave_supported(const camd_params& p) {
   if (p.polynomial_size == 1024 && p.torus_bits == 64)
     return p.glwe_dimension == 2 && p.pbs_level == 1 && p.pbs_base_log == 23;
-  return w4::supported(p) || tfhe_lib_instance(p);
+  return wave512_supported(p) || tfhe_lib_instance(p);
 }
 
 // every set with an instance gets it by default; the bit-exact kernels stay selectable
 bool wave_default(const camd_params& p) { return wave_supported(p); }
 
-size_t wave_tables_count(uint32_t N) { return N == 512 ? (size_t)w4::TAB_COUNT : (size_t)TAB_TOTAL; }
+size_t wave_tables_count(uint32_t N) { return N == 512 ? wave512_tables_count() : (size_t)TAB_TOTAL; }
 
 void wave_fill_tables(uint32_t N, double2* t) {
   if (N == 512) {
-    w4::fill_tables(t);
+    wave512_fill_tables(t);
     return;
   }
   for (int j = 0; j < 512; j++) {
@@ -1742,13 +1031,9 @@ int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, 
                         hipStream_t stream) {
   if (!wave_supported(p)) return fail(CAMD_EINVAL, "wave kernel: unsupported parameter set");
   const size_t polys = (size_t)p.lwe_dimension * p.pbs_level * (p.glwe_dimension + 1) * (p.glwe_dimension + 1);
-  if (w4::supported(p)) {
+  if (wave512_supported(p)) {
     if ((int)sizeof(T) * 8 != (int)p.torus_bits) return fail(CAMD_EINVAL, "wave kernel: torus width mismatch");
-    const size_t lds4 = w4::TAB_COUNT * sizeof(double2) + WAVES * 2 * w4::PLANE * sizeof(double);
-    hipLaunchKernelGGL(w4::bsk_fourier_kernel<T>, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds4, stream,
-                       bsk_std, fbsk, tables, polys);
-    CAMD_HIP(hipGetLastError());
-    return CAMD_OK;
+    return wave512_bsk_to_fourier<T>(bsk_std, fbsk, tables, polys, stream);
   }
   const size_t lds = TAB_COUNT * sizeof(double2) + WAVES * 2 * PLANE * sizeof(double);
   hipLaunchKernelGGL(wave_bsk_fourier_kernel<T>, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds, stream,
@@ -1760,11 +1045,10 @@ int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, 
 template <typename T>
 int wave_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
   if (a.count == 0) return CAMD_OK;
+  if (a.N == 512) return wave512_launch_pbs<T>(a, stream);
   if constexpr (sizeof(T) == 8) {
     if (a.N == 1024 && a.k == 2 && a.level == 1 && a.base_log == 23) return launch_instance<T, 2, 1, 23>(a, stream);
-    if (a.N == 512 && a.k == 3 && a.level == 1 && a.base_log == 18) return w4::launch<T, 3, 1, 18>(a, stream);
   } else {
-    if (a.N == 512 && a.k == 2 && a.level == 2 && a.base_log == 8) return w4::launch<T, 2, 2, 8>(a, stream);
     if (a.N == 1024 && a.k == 1 && a.level == 3 && a.base_log == 7) return launch_instance<T, 1, 3, 7>(a, stream);
   }
   return fail(CAMD_EINVAL, "wave kernel: no instance for this parameter set");

@@ -1,0 +1,591 @@
+// Programmable bootstrap, wave-per-ciphertext family, N = 512: the boolean default parameters
+// (32-bit torus, k = 2, two levels, base 2^8) and the three small shortint sets (64-bit torus, k = 3,
+// one level, base 2^18). Replaces FftEngine::discard_bootstrap_lwe_ciphertext as the reference calls
+// it at concrete-boolean/src/engine/bootstrapping/cpu.rs:231-236 and
+// concrete-shortint/src/engine/server_side/mod.rs:148-153.
+//
+// N = 512 instance (the boolean default parameters: 32-bit torus, k = 2, two levels, base 2^8).
+// Same schedule as wave_pbs_kernel_v2 — one wave per ciphertext, the transforms of a CMUX
+// interleaved as independent streams, the key rows of the next CMUX parked in accumulation
+// registers — with four points per lane: a 256-point transform is four radix-4 passes with three
+// exchanges, each a 4 x 4 transpose between the register index and one base-4 digit of the lane
+// index. With n = 64 a + lane, lane = 16 l2 + 4 l1 + l0 and f = k1 + 4 k2 + 16 k3 + 64 k4:
+//   pass 1 over a  (twiddle W_256^(lane k1)),      exchange register <-> l2,
+//   pass 2 over l2 (twiddle W_64^((lane & 15) k2)), exchange register <-> l1,
+//   pass 3 over l1 (twiddle W_16^((lane & 3) k3)),  exchange register <-> l0,
+//   pass 4 over l0; register k4 of lane 16 k1 + 4 k2 + k3 then holds X[f].
+// The inverse runs the mirror image (conjugate twiddles, same exchanges), unnormalised; the key
+// is pre-multiplied by 1/256. The exchange image is 4 rows of 64 values per plane, element
+// (r, lane) at r * 64 + (lane ^ (r << 2 * digit)): conflict-free for the lane groups of
+// ds_write_b64 and ds_read_b64 on both sides of every exchange (checked by enumeration).
+#include "wave_common.hpp"
+
+namespace camd {
+
+namespace {
+
+namespace w4 {
+constexpr int N = 512, M = 256, LOGN = 9;
+constexpr int TAB_TWIST = 0;                 // [j] e^{+i pi j / N}, j < 256
+constexpr int TAB_A = 256;                   // [k-1][lane] W_256^(lane k), k = 1..3
+constexpr int TAB_B = TAB_A + 3 * 64;        // [k-1][m]    W_64^(m k),  m < 16
+constexpr int TAB_C = TAB_B + 3 * 16;        // [k-1][m]    W_16^(m k),  m < 4
+constexpr int TAB_AT = TAB_C + 3 * 4;        // [k][lane] e^{i pi lane (1 - 4k) / N}, k = 0..3: TAB_A with the per-lane part of the twist folded in
+constexpr int TAB_COUNT = TAB_AT + 4 * 64;
+// the per-register part of the twist e^{i pi (64a + lane)/N} = e^{i pi a/8} e^{i pi lane/N}, a = 0..3
+constexpr double TWIST4_RE[4] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173};
+constexpr double TWIST4_IM[4] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
+constexpr int PLANE = 4 * 64;
+template <typename T, int K>
+constexpr size_t slab_bytes() { return (size_t)(K + 1) * N * sizeof(T) + 2 * PLANE * sizeof(double); }
+template <typename T, int K>
+constexpr size_t lds_bytes() { return TAB_COUNT * sizeof(double2) + WAVES * slab_bytes<T, K>(); }
+
+template <bool INV>
+__device__ __forceinline__ void dft4(double2 (&x)[4]) {
+  const double2 s0 = cadd(x[0], x[2]), d0 = csub(x[0], x[2]);
+  const double2 s1 = cadd(x[1], x[3]), d1 = csub(x[1], x[3]);
+  const double2 t = INV ? mul_pos_i(d1) : mul_neg_i(d1);
+  x[0] = cadd(s0, s1);
+  x[2] = csub(s0, s1);
+  x[1] = cadd(d0, t);
+  x[3] = csub(d0, t);
+}
+
+// transpose between the register index and base-4 digit DIGIT of the lane index, all streams
+template <int S, int DIGIT>
+__device__ __forceinline__ void exchange4(double2 (&x)[S][4], int lane, double* sre, double* sim) {
+  constexpr int SH = 2 * DIGIT;
+  const int d = (lane >> SH) & 3;
+  const int rest = lane & ~(3 << SH);
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int pos = r * 64 + (lane ^ (r << SH));
+      sre[pos] = x[s][r].x; sim[pos] = x[s][r].y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = d * 64 + (rest | ((j ^ d) << SH));
+      x[s][j] = make_double2(sre[idx], sim[idx]);
+    }
+  }
+}
+
+// FOLDED: the caller has applied only the per-register part of the twist (TWIST4_*); the per-lane
+// part commutes with the first radix-4 pass and comes with that pass's twiddles (TAB_AT), so no
+// twist table is read, for the same number of multiplications. The inverse mirrors it.
+template <int S, bool FOLDED = false>
+__device__ __forceinline__ void fft256_forward_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
+                                                     double* sim) {
+  double2 w[3], w0;
+  if (FOLDED) w0 = tab[TAB_AT + lane];
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = FOLDED ? tab[TAB_AT + k * 64 + lane] : tab[TAB_A + (k - 1) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    dft4<false>(x[s]);
+    if (FOLDED) x[s][0] = cmul(x[s][0], w0);
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
+  }
+  exchange4<S, 2>(x, lane, sre, sim);
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_B + (k - 1) * 16 + (lane & 15)];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    dft4<false>(x[s]);
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
+  }
+  exchange4<S, 1>(x, lane, sre, sim);
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_C + (k - 1) * 4 + (lane & 3)];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    dft4<false>(x[s]);
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
+  }
+  exchange4<S, 0>(x, lane, sre, sim);
+#pragma unroll
+  for (int s = 0; s < S; s++) dft4<false>(x[s]);
+}
+
+template <int S, bool FOLDED = false>
+__device__ __forceinline__ void fft256_inverse_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
+                                                     double* sim) {
+  double2 w[3], w0;
+#pragma unroll
+  for (int s = 0; s < S; s++) dft4<true>(x[s]);
+  exchange4<S, 0>(x, lane, sre, sim);
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_C + (k - 1) * 4 + (lane & 3)];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
+    dft4<true>(x[s]);
+  }
+  exchange4<S, 1>(x, lane, sre, sim);
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_B + (k - 1) * 16 + (lane & 15)];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
+    dft4<true>(x[s]);
+  }
+  exchange4<S, 2>(x, lane, sre, sim);
+  if (FOLDED) w0 = tab[TAB_AT + lane];
+#pragma unroll
+  for (int k = 1; k < 4; k++) w[k - 1] = FOLDED ? tab[TAB_AT + k * 64 + lane] : tab[TAB_A + (k - 1) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    if (FOLDED) x[s][0] = cmul_conj(x[s][0], w0);
+#pragma unroll
+    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
+    dft4<true>(x[s]);
+  }
+}
+__device__ __forceinline__ double2 twist4(double2 v, int a) {
+  return a == 0 ? v : cmul(v, make_double2(TWIST4_RE[a], TWIST4_IM[a]));
+}
+__device__ __forceinline__ double2 untwist4(double2 v, int a) {
+  return a == 0 ? v : cmul_conj(v, make_double2(TWIST4_RE[a], TWIST4_IM[a]));
+}
+
+// key conversion: one wave per polynomial, same transform, pre-scaled by 1/256
+template <typename T>
+__global__ __launch_bounds__(256) void bsk_fourier_kernel(const T* __restrict__ bsk, double2* __restrict__ out,
+                                                          const double2* __restrict__ tables, size_t polys) {
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = tables[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sre = (double*)(smem + TAB_COUNT * sizeof(double2)) + (size_t)wave * 2 * PLANE;
+  double* sim = sre + PLANE;
+  const size_t poly = (size_t)blockIdx.x * WAVES + wave;
+  if (poly >= polys) return;
+  using SG = typename Torus<T>::Signed;
+  constexpr double SCALE = (sizeof(T) == 8 ? 0x1.0p-64 : 0x1.0p-32) / 256.0;
+  const T* p = bsk + poly * N;
+  double2 x[1][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int j = 64 * a + lane;
+    const double re = signed_to_double((SG)p[j]) * SCALE;
+    const double im = signed_to_double((SG)p[j + M]) * SCALE;
+    x[0][a] = cmul(make_double2(re, im), tab[TAB_TWIST + j]);
+  }
+  fft256_forward_multi<1>(x, lane, tab, sre, sim);
+  double2* dst = out + poly * M;
+#pragma unroll
+  for (int g = 0; g < 4; g++) dst[g * 64 + lane] = x[0][g];
+}
+
+template <int BL>
+__device__ __forceinline__ int32_t next_digit(uint32_t& state) {
+  const uint32_t res = state & ((1u << BL) - 1u);
+  state >>= BL;
+  uint32_t carry = ((res - 1u) | state) & res;
+  carry >>= (BL - 1);
+  state += carry;
+  return (int32_t)(res - (carry << BL));
+}
+
+template <typename T, int K, int L, int BL>
+__global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
+  constexpr int R = K + 1;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = a.tables[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * slab_bytes<T, K>();
+  T* ct0 = (T*)slab;
+  double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
+  double* sim = sre + PLANE;
+  constexpr int S = R * L;          // forward streams: (level - 1) * R + row
+  constexpr int NS = S * R;         // key slabs per iteration: [level][row][col], 4 KiB each
+  constexpr int NA = NS < 14 ? NS : 14;   // slabs parked in accumulation registers (at most 224 AGPRs)
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  // persistent waves restart together per XCD (see wave_pbs_kernel_v2): key rows are then fetched
+  // into each L2 once instead of once per drifting wave
+  XcdRendezvous rendezvous;
+  if (a.scratch) rendezvous.enrol(a.scratch, lane);
+  const size_t per_round = (size_t)gridDim.x * WAVES;
+  uint32_t round = 0;
+  for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round, round++) {
+    const T* in = a.ct_in + ct * a.in_stride;
+    const uint32_t n = a.n;
+    const uint32_t lut_id = checked_lut_id(a, ct);
+    const T* lut = a.luts + (size_t)lut_id * (R * N);
+    {
+      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+      for (int idx = lane; idx < R * N; idx += 64) {
+        const int c = idx >> LOGN, j = idx & (N - 1);
+        ct0[idx] = rotated_coeff<T>(lut + (size_t)c * N, j, d0, N);
+      }
+    }
+    uint32_t i = 0;
+    T a_cur = wave_uniform(in[0]);
+    while (i < n && a_cur == 0) {
+      i++;
+      a_cur = wave_uniform(in[i]);
+    }
+    v4u bqa[NA][4];
+#pragma unroll
+    for (int sl = 0; sl < NA; sl++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(bqa[sl][g].x));
+    bool work = false;
+    uint32_t a_hat = 0, cur = 0;
+    for (;;) {
+      double2 x[S][4];
+      v4u bqv[NS - NA > 0 ? NS - NA : 1][4];
+      if (work) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const T* p = ct0 + r * N;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+            const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
+            const T rot0 = p[s0 & (N - 1)], rot1 = p[s1 & (N - 1)];
+            if constexpr (L == 1) {
+              const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, p[j0], s0);
+              const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, p[j1], s1);
+              x[r][q] = twist4(make_double2((double)g0, (double)g1), q);
+            } else {
+              const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
+              const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
+              uint32_t st0 = digit_state32<T, BL, L>((T)(r0 - p[j0]));
+              uint32_t st1 = digit_state32<T, BL, L>((T)(r1 - p[j1]));
+#pragma unroll
+              for (int l = L; l >= 1; l--) {
+                const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
+                x[(l - 1) * R + r][q] = twist4(make_double2((double)g0, (double)g1), q);
+              }
+            }
+          }
+        }
+        // the slabs that do not fit the accumulation registers: requested now, needed after the transforms
+#pragma unroll
+        for (int sl = NA; sl < NS; sl++) {
+          const char* base = (const char*)(a.fbsk + (size_t)cur * NS * M) + (size_t)sl * (M * sizeof(double2)) + 2048;
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                         : "=v"(bqv[sl - NA][g])
+                         : "v"(lane_off), "s"(base), "n"(g * 1024 - 2048)
+                         : "memory");
+        }
+        fft256_forward_multi<S, true>(x, lane, tab, sre, sim);
+      }
+      double2 acc[R][4];
+      if (!work) {
+#pragma unroll
+        for (int c = 0; c < R; c++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) acc[c][g] = make_double2(0.0, 0.0);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int sl = 0; sl < NA; sl++)
+          asm volatile("" : "+a"(bqa[sl][0]), "+a"(bqa[sl][1]), "+a"(bqa[sl][2]), "+a"(bqa[sl][3]));
+#pragma unroll
+        for (int sl = NA; sl < NS; sl++)
+          asm volatile("" : "+v"(bqv[sl - NA][0]), "+v"(bqv[sl - NA][1]), "+v"(bqv[sl - NA][2]), "+v"(bqv[sl - NA][3]));
+        auto key = [&](int s, int c, int g) -> double2 {
+          const int sl = s * R + c;
+          return as_double2(sl < NA ? bqa[sl < NA ? sl : 0][g] : bqv[sl >= NA ? sl - NA : 0][g]);
+        };
+#pragma unroll
+        for (int c = 0; c < R; c++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            double2 v = cmul(key(0, c, g), x[0][g]);
+#pragma unroll
+            for (int s = 1; s < S; s++) v = cfma(key(s, c, g), x[s][g], v);
+            acc[c][g] = v;
+          }
+      }
+      // key rows of the next active iteration (index i), if any
+      const bool more = i < n;
+      const char* ggsw = (const char*)(a.fbsk + (size_t)(more ? i : 0) * NS * M);
+      if (more) {
+#pragma unroll
+        for (int sl = 0; sl < NA; sl++) {
+          const char* base = ggsw + (size_t)sl * (M * sizeof(double2)) + 2048;
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                         : "=a"(bqa[sl][g])
+                         : "v"(lane_off), "s"(base), "n"(g * 1024 - 2048)
+                         : "memory");
+        }
+      }
+      const uint32_t next_i = i;
+      const uint32_t next_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
+      if (more) {
+        i++;
+        a_cur = wave_uniform(in[i]);
+        while (i < n && a_cur == 0) {
+          i++;
+          a_cur = wave_uniform(in[i]);
+        }
+      }
+      fft256_inverse_multi<R, true>(acc, lane, tab, sre, sim);
+#pragma unroll
+      for (int c = 0; c < R; c++) {
+        T* pc = ct0 + c * N;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t j0 = 64 * q + lane;
+          const double2 v = untwist4(acc[c][q], q);
+          pc[j0] = torus_accumulate(pc[j0], v.x);
+          pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
+        }
+      }
+      if (!more) break;
+      work = true;
+      a_hat = next_hat;
+      cur = next_i;
+    }
+    T* out = a.ct_out + ct * a.out_stride;
+    for (int idx = lane; idx < K * N; idx += 64) {
+      const int c = idx >> LOGN, j = idx & (N - 1);
+      const T* p = ct0 + c * N;
+      out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
+    }
+    if (lane == 0) out[K * N] = ct0[K * N];
+    if ((size_t)(round + 1) * per_round < a.count) rendezvous.arrive_and_wait(round, lane);
+  }
+}
+
+// Latency variant (see wave_pbs_kernel_lat): k+1 waves per ciphertext, wave c owning polynomial
+// c. It transforms the L digit polynomials of its own polynomial, publishes them, and after the
+// barrier accumulates column c over all (k+1) L spectra in the order of pbs_kernel, so both give
+// the same ciphertext words.
+template <typename T>
+constexpr size_t lat_slab_bytes() { return (size_t)N * sizeof(T) + 2 * PLANE * sizeof(double); }
+template <typename T, int K, int L>
+constexpr size_t lat_lds_bytes() {
+  return TAB_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T>() + 2 * (size_t)(K + 1) * L * M * sizeof(double2);
+}
+
+template <typename T, int K, int L, int BL>
+__global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
+  constexpr int R = K + 1, S = R * L, NS = S * R;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * R) tab[t] = a.tables[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = the polynomial this wave owns
+  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T>();
+  T* stage = (T*)slab;
+  double* sre = (double*)(slab + (size_t)N * sizeof(T));
+  double* sim = sre + PLANE;
+  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T>());  // [2][S][4][64]
+  const uint32_t n = a.n;
+  uint32_t image = 0;
+
+  for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
+    const T* in = a.ct_in + ct * a.in_stride;
+    const uint32_t lut_id = checked_lut_id(a, ct);
+    const T* lut = a.luts + (size_t)lut_id * (R * N) + (size_t)wave * N;
+    // acc[2q] = coefficient 64q + lane, acc[2q+1] = coefficient 64q + lane + N/2 of the own polynomial
+    T acc[8];
+    {
+      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        acc[2 * q] = rotated_coeff<T>(lut, 64 * q + lane, d0, N);
+        acc[2 * q + 1] = rotated_coeff<T>(lut, 64 * q + lane + M, d0, N);
+      }
+    }
+    T a_next = wave_uniform(in[0]);
+    for (uint32_t i = 0; i < n; i++) {
+      const T a_cur = a_next;
+      a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
+      if (a_cur == 0) continue;           // skipped by every wave of the group alike
+      const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
+
+      // column `wave` of key row i, every stream
+      const double2* key = a.fbsk + (size_t)i * NS * M + (size_t)wave * M + lane;
+      double2 kk[S][4];
+#pragma unroll
+      for (int st = 0; st < S; st++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) kk[st][g] = key[(size_t)(st * R) * M + g * 64];
+
+      double2 x[L][4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        stage[64 * q + lane] = acc[2 * q];
+        stage[64 * q + lane + M] = acc[2 * q + 1];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+        const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
+        const T rot0 = stage[s0 & (N - 1)], rot1 = stage[s1 & (N - 1)];
+        if constexpr (L == 1) {
+          const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, acc[2 * q], s0);
+          const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, acc[2 * q + 1], s1);
+          x[0][q] = twist4(make_double2((double)g0, (double)g1), q);
+        } else {
+          const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
+          const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
+          uint32_t st0 = digit_state32<T, BL, L>((T)(r0 - acc[2 * q]));
+          uint32_t st1 = digit_state32<T, BL, L>((T)(r1 - acc[2 * q + 1]));
+#pragma unroll
+          for (int l = L; l >= 1; l--) {
+            const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
+            x[l - 1][q] = twist4(make_double2((double)g0, (double)g1), q);
+          }
+        }
+      }
+      fft256_forward_multi<L, true>(x, lane, tab, sre, sim);
+
+      double2* img = spectra + (size_t)image * (S * M);
+#pragma unroll
+      for (int l = 0; l < L; l++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) img[((l * R + wave) * 4 + g) * 64 + lane] = x[l][g];
+      __syncthreads();
+      image ^= 1u;
+
+      double2 y[1][4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        double2 v = cmul(kk[0][g], img[(0 * 4 + g) * 64 + lane]);
+#pragma unroll
+        for (int st = 1; st < S; st++) v = cfma(kk[st][g], img[(st * 4 + g) * 64 + lane], v);
+        y[0][g] = v;
+      }
+      fft256_inverse_multi<1, true>(y, lane, tab, sre, sim);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double2 v = untwist4(y[0][q], q);
+        acc[2 * q] = torus_accumulate(acc[2 * q], v.x);
+        acc[2 * q + 1] = torus_accumulate(acc[2 * q + 1], v.y);
+      }
+    }
+
+    // sample extraction of coefficient 0: out[c N + (N - j) mod N] = (j == 0) ? p[j] : -p[j]
+    T* out = a.ct_out + ct * a.out_stride;
+    if (wave < K) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+        out[(size_t)wave * N + ((N - j0) & (N - 1))] = (j0 == 0) ? acc[2 * q] : (T)(T(0) - acc[2 * q]);
+        out[(size_t)wave * N + (N - j1)] = (T)(T(0) - acc[2 * q + 1]);
+      }
+    } else if (lane == 0) {
+      out[K * N] = acc[0];
+    }
+  }
+}
+
+inline bool supported(const camd_params& p) {
+  if (p.polynomial_size != 512) return false;
+  if (p.torus_bits == 32) return p.glwe_dimension == 2 && p.pbs_level == 2 && p.pbs_base_log == 8;
+  return p.glwe_dimension == 3 && p.pbs_level == 1 && p.pbs_base_log == 18;   // the three small shortint sets
+}
+
+inline void fill_tables(double2* t) {
+  for (int j = 0; j < 256; j++) {
+    const double ang = M_PI * (double)j / (double)N;
+    t[TAB_TWIST + j] = make_double2(std::cos(ang), std::sin(ang));
+  }
+  for (int k = 1; k < 4; k++) {
+    for (int m = 0; m < 64; m++) {
+      const double ang = -2.0 * M_PI * (double)(m * k) / 256.0;
+      t[TAB_A + (k - 1) * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+    for (int m = 0; m < 16; m++) {
+      const double ang = -2.0 * M_PI * (double)(m * k) / 64.0;
+      t[TAB_B + (k - 1) * 16 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+    for (int m = 0; m < 4; m++) {
+      const double ang = -2.0 * M_PI * (double)(m * k) / 16.0;
+      t[TAB_C + (k - 1) * 4 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+  }
+  for (int k = 0; k < 4; k++)
+    for (int m = 0; m < 64; m++) {
+      const double ang = M_PI * (double)(m * (1 - 4 * k)) / (double)N;
+      t[TAB_AT + k * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
+    }
+}
+
+template <typename T, int K, int L, int BL>
+int launch(const PbsLaunch<T>& a, hipStream_t stream) {
+  constexpr size_t lds = lds_bytes<T, K>();
+  static_assert(lds <= 160 * 1024, "LDS budget exceeded");
+  auto kern = pbs_kernel<T, K, L, BL>;
+  if (lds > 64 * 1024) CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int dev = 0, cus = 0;
+  CAMD_HIP(hipGetDevice(&dev));
+  CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  constexpr int lat_fit = (int)((160 * 1024) / lat_lds_bytes<T, K, L>());
+  if (a.count <= wave_latency_limit(cus, lat_fit)) {
+    constexpr size_t ldsl = lat_lds_bytes<T, K, L>();
+    static_assert(ldsl <= 160 * 1024, "LDS budget exceeded");
+    auto kernl = pbs_kernel_lat<T, K, L, BL>;
+    if (ldsl > 64 * 1024) CAMD_HIP(hipFuncSetAttribute((const void*)kernl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl));
+    hipLaunchKernelGGL(kernl, dim3((unsigned)a.count), dim3(64 * (K + 1)), ldsl, stream, a);
+    CAMD_HIP(hipGetLastError());
+    return CAMD_OK;
+  }
+  const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
+  const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // one wave per SIMD (512 registers)
+  if (persistent < grid) {
+    if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
+    CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
+  }
+  hipLaunchKernelGGL(kern, dim3(persistent), dim3(256), lds, stream, a);
+  CAMD_HIP(hipGetLastError());
+  return CAMD_OK;
+}
+}  // namespace w4
+
+}  // namespace
+
+bool wave512_supported(const camd_params& p) { return w4::supported(p); }
+size_t wave512_tables_count() { return (size_t)w4::TAB_COUNT; }
+void wave512_fill_tables(double2* t) { w4::fill_tables(t); }
+
+template <typename T>
+int wave512_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream) {
+  const size_t lds = w4::TAB_COUNT * sizeof(double2) + WAVES * 2 * w4::PLANE * sizeof(double);
+  hipLaunchKernelGGL(w4::bsk_fourier_kernel<T>, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds, stream,
+                     bsk_std, fbsk, tables, polys);
+  CAMD_HIP(hipGetLastError());
+  return CAMD_OK;
+}
+
+template <typename T>
+int wave512_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
+  if constexpr (sizeof(T) == 8) {
+    if (a.k == 3 && a.level == 1 && a.base_log == 18) return w4::launch<T, 3, 1, 18>(a, stream);
+  } else {
+    if (a.k == 2 && a.level == 2 && a.base_log == 8) return w4::launch<T, 2, 2, 8>(a, stream);
+  }
+  return fail(CAMD_EINVAL, "wave kernel: no instance for this parameter set");
+}
+
+template int wave512_bsk_to_fourier<uint64_t>(const uint64_t*, double2*, const double2*, size_t, hipStream_t);
+template int wave512_bsk_to_fourier<uint32_t>(const uint32_t*, double2*, const double2*, size_t, hipStream_t);
+template int wave512_launch_pbs<uint64_t>(const PbsLaunch<uint64_t>&, hipStream_t);
+template int wave512_launch_pbs<uint32_t>(const PbsLaunch<uint32_t>&, hipStream_t);
+
+}  // namespace camd

@@ -12,6 +12,7 @@ const SOURCES: [&str; 9] = [
     "pbs_generic.hip",
     "pbs_block.hip",
     "pbs_wave.hip",
+    "pbs_wave512.hip",
     "probe.hip",
     "client.cpp",
 ];

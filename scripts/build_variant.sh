@@ -7,6 +7,6 @@ NAME=$1; shift
 mkdir -p $ROOT/build
 cd $ROOT/concrete_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function "$@" -x hip \
-  abi.hip keyswitch.hip keyswitch_mfma.hip linear.hip pbs_generic.hip pbs_block.hip pbs_wave.hip probe.hip client.cpp \
+  abi.hip keyswitch.hip keyswitch_mfma.hip linear.hip pbs_generic.hip pbs_block.hip pbs_wave.hip pbs_wave512.hip probe.hip client.cpp \
   -o $ROOT/build/libconcrete_amd_$NAME.so -lpthread
 echo built $ROOT/build/libconcrete_amd_$NAME.so

@@ -266,8 +266,8 @@ def test_wave512_kernel_keeps_parked_key_registers_untouched(tmp_path):
     import re
     import subprocess
 
-    src = os.path.join(ROOT, "concrete_amd", "csrc", "pbs_wave.hip")
-    out = tmp_path / "pbs_wave.s"
+    src = os.path.join(ROOT, "concrete_amd", "csrc", "pbs_wave512.hip")
+    out = tmp_path / "pbs_wave512.s"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src,
                     "-o", str(out)], check=True, capture_output=True)
     text = out.read_text()
