@@ -28,22 +28,6 @@ inline size_t wave_latency_limit(int cus, int fit) {
 __device__ __forceinline__ double2 mul_neg_i(double2 v) { return make_double2(v.y, -v.x); }
 __device__ __forceinline__ double2 mul_pos_i(double2 v) { return make_double2(-v.y, v.x); }
 
-// f64 (torus units) -> torus word by magic-constant additions: with fr = t mod 1 in [0, 1), adding
-// 1.5*2^20 leaves round(fr*2^32) in the low dword of the sum (a carry out of it is a whole turn of
-// the torus); the remainder, added to 1.5*2^-12, leaves round(rem*2^64) in its mantissa.
-template <typename T>
-__device__ __forceinline__ T from_torus_fast(double t);
-template <>
-__device__ __forceinline__ uint64_t from_torus_fast<uint64_t>(double t) {
-  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
-  const double a = fr + 0x1.8p20;
-  const uint32_t q = (uint32_t)__double2loint(a);
-  const double rem = fr - (a - 0x1.8p20);
-  const double b = rem + 0x1.8p-12;
-  const uint32_t lo = (uint32_t)__double2loint(b);
-  const uint32_t hi = q + (uint32_t)((__double2hiint(b) & 0xFFFFF) - 0x80000);
-  return ((uint64_t)hi << 32) | lo;
-}
 // acc += t (torus units) rounded to 52 fractional bits, in four instructions. With fr = t mod 1,
 // b = 1 + fr has the exponent of 1.0, or is exactly 2.0, so its mantissa m is fr in units of 2^-52
 // (zero for b = 2.0: a whole turn) and the addend is m << 12: the low dword of b times 2^12 goes in
@@ -76,14 +60,11 @@ __device__ __forceinline__ uint64_t torus_accumulate_end(const TorusSum& s) {
 __device__ __forceinline__ uint64_t torus_accumulate(uint64_t acc, double t) {
   return torus_accumulate_end(torus_accumulate_begin(acc, t));
 }
+// 32-bit torus: with fr = t mod 1 in [0, 1), adding 1.5*2^20 leaves round(fr*2^32) in the low dword
+// of the sum (a carry out of it is a whole turn of the torus)
 __device__ __forceinline__ uint32_t torus_accumulate(uint32_t acc, double t) {
-  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
+  const double fr = __builtin_amdgcn_fract(t);
   return acc + (uint32_t)__double2loint(fr + 0x1.8p20);
-}
-template <>
-__device__ __forceinline__ uint32_t from_torus_fast<uint32_t>(double t) {
-  const double fr = __builtin_amdgcn_fract(t);   // t mod 1 in [0, 1): one instruction, and the torus word is taken mod 2^BITS anyway
-  return (uint32_t)__double2loint(fr + 0x1.8p20);
 }
 
 // Decomposition state in 32 bits. Only the top BL*L bits of the word (plus the rounding bit
