@@ -43,12 +43,18 @@ constexpr int TAB_TW1 = TAB_TW0 + 7 * 64;      // [b-1][m]    e^{-2 pi i m b / 6
 constexpr int TAB_COUNT = TAB_TW1 + 7 * 8;     // what the key-conversion kernel stages in LDS
 // The bootstrap kernels split the twist e^{i pi (64a+lane)/N} into a per-register part
 // e^{i pi a/16}, eight compile-time constants, and a per-lane part e^{i pi lane/N}. The per-lane part
-// commutes with the first radix-8 pass (it is the same for the eight inputs of a lane), so it is
-// folded into that pass's output twiddles: [b][lane] e^{i pi lane (1 - 4b)/N}, b = 0..7. No twist
-// table is read at all, for the same number of multiplications.
-constexpr int TAB_TW0T = TAB_COUNT;
-constexpr int TAB_TOTAL = TAB_TW0T + 8 * 64;
-constexpr int TABV2_TW0T = 0, TABV2_TW1 = 8 * 64, TABV2_COUNT = TABV2_TW1 + 7 * 8;   // their LDS image
+// commutes with the first radix-8 pass (it is the same for the eight inputs of a lane), so it joins
+// that pass's output twiddles: e^{i pi lane (1 - 4b)/N} for output b. No twist table is read.
+// Every twiddle is applied on the receiving side of the exchange that follows it, as the input
+// factor of the next radix-8 pass, in the folded form of dft8_tw below. The constants of a pass
+// are stored as pairs of doubles: (t1,t2) (t3,t4) (t5,t6) (t7,c4) (r51,r62) (r73,c2) (r31,c1)
+// (hc1,-) and, where input 0 has a twiddle of its own, w0.
+constexpr int TWS_A = 0;                       // [pair 9][lane]: forward, second pass: input q of lane (hi,lo) carries e^{i pi (8q+lo)(1-4hi)/N}
+constexpr int TWS_B = TWS_A + 9 * 64;          // [pair 8][lo]:   input q carries e^{-2 pi i lo q/64} (forward third pass; conjugated: inverse second pass)
+constexpr int TWS_C = TWS_B + 8 * 8;           // [pair 9][lane]: inverse, third pass: input b carries the conjugate of e^{i pi lane (1-4b)/N}
+constexpr int TWS_COUNT = TWS_C + 9 * 64;      // the bootstrap kernels' LDS image
+constexpr int TAB_TWS = TAB_COUNT;             // where that image starts in the table buffer
+constexpr int TAB_TOTAL = TAB_TWS + TWS_COUNT;
 
 constexpr double HALF_SQRT2 = 0.70710678118654752440;
 // e^{i pi a / 16}, a = 0..7
@@ -100,23 +106,14 @@ __device__ __forceinline__ void dft8(double2 (&x)[8]) {
   }
 }
 
-// Forward transform of 512 points held as x[a] = point 64a + lane.
-// Result: x[g] = X[64 g + 8 (lane & 7) + (lane >> 3)].
-// FOLDED: `tab` is the bootstrap kernels' own image (TABV2_*): the caller has applied only the
-// per-register part of the twist and the per-lane part comes with the first pass's twiddles.
-template <bool FOLDED = false>
+// Forward transform of 512 points held as x[a] = point 64a + lane (twist already applied).
+// Result: x[g] = X[64 g + 8 (lane & 7) + (lane >> 3)]. Used by the key conversion.
 __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const double2* tab, double* sre,
                                                double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
-  constexpr int TW1 = FOLDED ? TABV2_TW1 : TAB_TW1;
   dft8<false>(x);
-  if (FOLDED) {
 #pragma unroll
-    for (int b = 0; b < 8; b++) x[b] = cmul(x[b], tab[TABV2_TW0T + b * 64 + lane]);
-  } else {
-#pragma unroll
-    for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
-  }
+  for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
   // exchange 1: register index b <-> lane bits 5:3
 #pragma unroll
   for (int b = 0; b < 8; b++) {
@@ -129,7 +126,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
   }
   dft8<false>(x);
 #pragma unroll
-  for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TW1 + (b - 1) * 8 + lo]);
+  for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tab[TAB_TW1 + (b - 1) * 8 + lo]);
   // exchange 2: register index b' <-> lane bits 2:0 (XOR keeps both sides conflict-free)
 #pragma unroll
   for (int b = 0; b < 8; b++) {
@@ -144,12 +141,127 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], int lane, const 
   dft8<false>(x);
 }
 
-// Unnormalised inverse of fft512_forward: spectrum in, x[a] = 512 * point (64a + lane) out.
-template <bool FOLDED = false>
-__device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const double2* tab, double* sre,
-                                               double* sim) {
+// ---- radix-8 pass with its input twiddles folded into the butterflies ----
+// A twiddle w = c (1 + i t) (c the cosine, t the tangent of its angle) times x is c y with
+// y = (x.re - t x.im, x.im + t x.re): two fused multiply-adds. The real factor c is not applied
+// there. The butterfly stage that combines y_b with its partner y_a takes the ratio as the
+// multiplier of a fused multiply-add, y_a + (c_b / c_a) y_b, and the factor c_a left on the pair
+// moves on to the next stage in the same way, until it meets the chain of input 0, whose factor is
+// 1. Every addition of the 8-point transform becomes a fused multiply-add and the seven complex
+// multiplications in front of it take 14 instructions instead of 28; the result is the transform
+// of the twiddled inputs with nothing left to apply. A twiddle of exactly -i (c = 0) is stored
+// with c = 2^-60: its tangent is then finite and the value moves by 2^-60 of itself.
+struct Tw8 {
+  double t[8];                                  // t[b], b = 1..7: tangent of the angle of input b
+  double c4, r51, r62, r73, c2, r31, c1, hc1;   // c_b: cosine of input b; r_ba = c_b / c_a; hc1 = c1 / sqrt 2
+  double2 w0;                                   // twiddle of input 0, for the passes where it is not 1
+};
+__device__ __forceinline__ double2 rfma(double s, double2 a, double2 b) {   // s a + b, s real
+  return make_double2(fma(s, a.x, b.x), fma(s, a.y, b.y));
+}
+// INV: the inputs carry the conjugates of the twiddles and the transform is e^{+2 pi i jk/8}.
+template <bool INV, bool X0TW>
+__device__ __forceinline__ void dft8_tw(double2 (&x)[8], const Tw8& k) {
+  double2 y[8];
+  y[0] = X0TW ? (INV ? cmul_conj(x[0], k.w0) : cmul(x[0], k.w0)) : x[0];
+#pragma unroll
+  for (int b = 1; b < 8; b++)
+    y[b] = INV ? make_double2(fma(k.t[b], x[b].y, x[b].x), fma(-k.t[b], x[b].x, x[b].y))
+               : make_double2(fma(-k.t[b], x[b].y, x[b].x), fma(k.t[b], x[b].x, x[b].y));
+  // stage 1; capital letters carry a pending factor: A1, D5 c1; A2, D6 c2; A3, D7 c3
+  const double2 a0 = rfma(k.c4, y[4], y[0]), a4 = rfma(-k.c4, y[4], y[0]);
+  const double2 A1 = rfma(k.r51, y[5], y[1]), D5 = rfma(-k.r51, y[5], y[1]);
+  const double2 A2 = rfma(k.r62, y[6], y[2]), D6 = rfma(-k.r62, y[6], y[2]);
+  const double2 A3 = rfma(k.r73, y[7], y[3]), D7 = rfma(-k.r73, y[7], y[3]);
+  double2 S5, S7;   // sqrt(2) D5 W8^(+-1) (pending c1), sqrt(2) D7 W8^(+-3) (pending c3)
+  if (!INV) {
+    S5 = make_double2(D5.x + D5.y, D5.y - D5.x);
+    S7 = make_double2(D7.y - D7.x, -(D7.x + D7.y));
+  } else {
+    S5 = make_double2(D5.x - D5.y, D5.x + D5.y);
+    S7 = make_double2(-(D7.x + D7.y), D7.x - D7.y);
+  }
+  const double2 A6 = INV ? mul_pos_i(D6) : mul_neg_i(D6);
+  // stage 2; B1, E3, U, V carry c1
+  const double2 b0 = rfma(k.c2, A2, a0), b2 = rfma(-k.c2, A2, a0);
+  const double2 B1 = rfma(k.r31, A3, A1), E3 = rfma(-k.r31, A3, A1);
+  const double2 b4 = rfma(k.c2, A6, a4), b6 = rfma(-k.c2, A6, a4);
+  const double2 U = rfma(k.r31, S7, S5), V = rfma(-k.r31, S7, S5);
+  const double2 B3 = INV ? mul_pos_i(E3) : mul_neg_i(E3);
+  // stage 3
+  x[0] = rfma(k.c1, B1, b0);
+  x[4] = rfma(-k.c1, B1, b0);
+  x[2] = rfma(k.c1, B3, b2);
+  x[6] = rfma(-k.c1, B3, b2);
+  x[1] = rfma(k.hc1, U, b4);
+  x[5] = rfma(-k.hc1, U, b4);
+  if (!INV) {
+    x[3] = make_double2(fma(k.hc1, V.y, b6.x), fma(-k.hc1, V.x, b6.y));
+    x[7] = make_double2(fma(-k.hc1, V.y, b6.x), fma(k.hc1, V.x, b6.y));
+  } else {
+    x[3] = make_double2(fma(-k.hc1, V.y, b6.x), fma(k.hc1, V.x, b6.y));
+    x[7] = make_double2(fma(k.hc1, V.y, b6.x), fma(-k.hc1, V.x, b6.y));
+  }
+}
+// the constants of a pass from the LDS image: `p` points at the lane's entry of pair 0
+template <bool X0TW>
+__device__ __forceinline__ Tw8 load_tw8(const double2* p, int stride) {
+  Tw8 k;
+  const double2 p0 = p[0], p1 = p[stride], p2 = p[2 * stride], p3 = p[3 * stride], p4 = p[4 * stride],
+                p5 = p[5 * stride], p6 = p[6 * stride], p7 = p[7 * stride];
+  k.t[0] = 0.0;
+  k.t[1] = p0.x; k.t[2] = p0.y; k.t[3] = p1.x; k.t[4] = p1.y; k.t[5] = p2.x; k.t[6] = p2.y; k.t[7] = p3.x;
+  k.c4 = p3.y; k.r51 = p4.x; k.r62 = p4.y; k.r73 = p5.x; k.c2 = p5.y; k.r31 = p6.x; k.c1 = p6.y; k.hc1 = p7.x;
+  k.w0 = X0TW ? p[8 * stride] : make_double2(1.0, 0.0);
+  return k;
+}
+// the per-register part of the twist, e^{i pi a/16} on input a of the first forward pass: compile-time constants
+__device__ __forceinline__ Tw8 twist_tw8() {
+  Tw8 k;
+  k.t[0] = 0.0;
+#pragma unroll
+  for (int b = 1; b < 8; b++) k.t[b] = TWIST8_IM[b] / TWIST8_RE[b];
+  k.c4 = TWIST8_RE[4]; k.r51 = TWIST8_RE[5] / TWIST8_RE[1]; k.r62 = TWIST8_RE[6] / TWIST8_RE[2];
+  k.r73 = TWIST8_RE[7] / TWIST8_RE[3]; k.c2 = TWIST8_RE[2]; k.r31 = TWIST8_RE[3] / TWIST8_RE[1];
+  k.c1 = TWIST8_RE[1]; k.hc1 = TWIST8_RE[1] * HALF_SQRT2;
+  k.w0 = make_double2(1.0, 0.0);
+  return k;
+}
+
+// Twisted forward transform for the bootstrap kernels: x[a] = (untwisted) point 64a + lane in,
+// spectrum out in the order of fft512_forward. `tab` is the kernels' own LDS image (TWS_*).
+__device__ __forceinline__ void fft512_forward_tw(double2 (&x)[8], int lane, const double2* tab, double* sre,
+                                                  double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
-  constexpr int TW1 = FOLDED ? TABV2_TW1 : TAB_TW1;
+  dft8_tw<false, false>(x, twist_tw8());
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    sre[b * ROW + lane] = x[b].x; sim[b * ROW + lane] = x[b].y;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int idx = hi * ROW + q * 8 + lo;
+    x[q] = make_double2(sre[idx], sim[idx]);
+  }
+  dft8_tw<false, true>(x, load_tw8<true>(tab + TWS_A + lane, 64));
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    const int idx = hi * ROW + b * 8 + (lo ^ b);
+    sre[idx] = x[b].x; sim[idx] = x[b].y;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int idx = hi * ROW + lo * 8 + (q ^ lo);
+    x[q] = make_double2(sre[idx], sim[idx]);
+  }
+  dft8_tw<false, false>(x, load_tw8<false>(tab + TWS_B + lo, 8));
+}
+
+// Unnormalised inverse of fft512_forward_tw up to the per-register part of the twist:
+// spectrum in, x[a] = 512 e^{i pi a/16} * point (64a + lane) out (the caller applies untwist8).
+__device__ __forceinline__ void fft512_inverse_tw(double2 (&x)[8], int lane, const double2* tab, double* sre,
+                                                  double* sim) {
+  const int hi = lane >> 3, lo = lane & 7;
   dft8<true>(x);
 #pragma unroll
   for (int q = 0; q < 8; q++) {
@@ -161,9 +273,7 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
     const int idx = hi * ROW + b * 8 + (lo ^ b);
     x[b] = make_double2(sre[idx], sim[idx]);
   }
-#pragma unroll
-  for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TW1 + (b - 1) * 8 + lo]);
-  dft8<true>(x);
+  dft8_tw<true, false>(x, load_tw8<false>(tab + TWS_B + lo, 8));
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + q * 8 + lo;
@@ -171,26 +281,15 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], int lane, const 
   }
 #pragma unroll
   for (int b = 0; b < 8; b++) x[b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
-  if (FOLDED) {
-#pragma unroll
-    for (int b = 0; b < 8; b++) x[b] = cmul_conj(x[b], tab[TABV2_TW0T + b * 64 + lane]);
-  } else {
-#pragma unroll
-    for (int b = 1; b < 8; b++) x[b] = cmul_conj(x[b], tab[TAB_TW0 + (b - 1) * 64 + lane]);
-  }
-  dft8<true>(x);
+  dft8_tw<true, true>(x, load_tw8<true>(tab + TWS_C + lane, 64));
 }
-// the per-register part of the twist and its inverse (a is a compile-time index at every call site)
-__device__ __forceinline__ double2 twist8(double2 v, int a) {
-  return a == 0 ? v : cmul(v, make_double2(TWIST8_RE[a], TWIST8_IM[a]));
-}
+// the inverse of the per-register part of the twist (a is a compile-time index at every call site)
 __device__ __forceinline__ double2 untwist8(double2 v, int a) {
   return a == 0 ? v : cmul_conj(v, make_double2(TWIST8_RE[a], TWIST8_IM[a]));
 }
-// the bootstrap kernels' LDS image of the tables: folded first-pass twiddles, second-pass twiddles
+// the bootstrap kernels' LDS image of the tables
 __device__ __forceinline__ void stage_folded_tables(double2* tab, const double2* __restrict__ tables, int threads) {
-  for (int t = threadIdx.x; t < TABV2_COUNT; t += threads)
-    tab[t] = tables[t < TABV2_TW1 ? TAB_TW0T + t : TAB_TW1 + (t - TABV2_TW1)];
+  for (int t = threadIdx.x; t < TWS_COUNT; t += threads) tab[t] = tables[TAB_TWS + t];
 }
 
 template <typename T, int K>
@@ -199,7 +298,7 @@ constexpr size_t wave_slab_bytes() {
 }
 template <typename T, int K>
 constexpr size_t wave_lds_bytes() {
-  return TABV2_COUNT * sizeof(double2) + WAVES * wave_slab_bytes<T, K>();
+  return TWS_COUNT * sizeof(double2) + WAVES * wave_slab_bytes<T, K>();
 }
 
 // ---- key conversion: one wave per polynomial, same transform, key pre-scaled by 1/512 ----
@@ -248,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
   const size_t ct = (size_t)blockIdx.x * WAVES + wave;
   if (ct >= a.count) return;
 
-  char* slab = smem + TABV2_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
+  char* slab = smem + TWS_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
   T* ct0 = (T*)slab;
   double* sre = (double*)(slab + (size_t)(K + 1) * N * sizeof(T));
   double* sim = sre + PLANE;
@@ -319,9 +418,9 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const int32_t g0 = digit_next32<BL, L>(st0[q]), g1 = digit_next32<BL, L>(st1[q]);
-          x[q] = twist8(make_double2((double)g0, (double)g1), q);
+          x[q] = make_double2((double)g0, (double)g1);   // the twist is in the transform
         }
-        fft512_forward<true>(x, lane, tab, sre, sim);
+        fft512_forward_tw(x, lane, tab, sre, sim);
 #pragma unroll
         for (int c = 0; c <= K; c++) {
 #pragma unroll
@@ -356,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
           z[g] = acc[c][g];
           acc[c][g] = make_double2(0.0, 0.0);
         }
-        fft512_inverse<true>(z, lane, tab, sre, sim);
+        fft512_inverse_tw(z, lane, tab, sre, sim);
         T* pc = ct0 + c * N;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -393,50 +492,46 @@ template <int S>
 __device__ __forceinline__ void fft512_forward_multi(double2 (&x)[S][8], int lane, const double2* tab, double* sre,
                                                      double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
-  double2 w[8];
+  {
+    const Tw8 k = twist_tw8();
 #pragma unroll
-  for (int b = 0; b < 8; b++) w[b] = tab[TABV2_TW0T + b * 64 + lane];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-    dft8<false>(x[s]);
-#pragma unroll
-    for (int b = 0; b < 8; b++) x[s][b] = cmul(x[s][b], w[b]);
+    for (int s = 0; s < S; s++) dft8_tw<false, false>(x[s], k);
   }
+  {
+    const Tw8 k = load_tw8<true>(tab + TWS_A + lane, 64);
 #pragma unroll
-  for (int s = 0; s < S; s++) {
+    for (int s = 0; s < S; s++) {
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
-      sre[b * ROW + lane] = x[s][b].x; sim[b * ROW + lane] = x[s][b].y;
+      for (int b = 0; b < 8; b++) {
+        sre[b * ROW + lane] = x[s][b].x; sim[b * ROW + lane] = x[s][b].y;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int idx = hi * ROW + q * 8 + lo;
+        x[s][q] = make_double2(sre[idx], sim[idx]);
+      }
     }
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int idx = hi * ROW + q * 8 + lo;
-      x[s][q] = make_double2(sre[idx], sim[idx]);
-    }
+    for (int s = 0; s < S; s++) dft8_tw<false, true>(x[s], k);
   }
+  {
+    const Tw8 k = load_tw8<false>(tab + TWS_B + lo, 8);
 #pragma unroll
-  for (int b = 1; b < 8; b++) w[b] = tab[TABV2_TW1 + (b - 1) * 8 + lo];
+    for (int s = 0; s < S; s++) {
 #pragma unroll
-  for (int s = 0; s < S; s++) {
-    dft8<false>(x[s]);
+      for (int b = 0; b < 8; b++) {
+        const int idx = hi * ROW + b * 8 + (lo ^ b);
+        sre[idx] = x[s][b].x; sim[idx] = x[s][b].y;
+      }
 #pragma unroll
-    for (int b = 1; b < 8; b++) x[s][b] = cmul(x[s][b], w[b]);
-  }
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-      const int idx = hi * ROW + b * 8 + (lo ^ b);
-      sre[idx] = x[s][b].x; sim[idx] = x[s][b].y;
+      for (int q = 0; q < 8; q++) {
+        const int idx = hi * ROW + lo * 8 + (q ^ lo);
+        x[s][q] = make_double2(sre[idx], sim[idx]);
+      }
     }
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int idx = hi * ROW + lo * 8 + (q ^ lo);
-      x[s][q] = make_double2(sre[idx], sim[idx]);
-    }
+    for (int s = 0; s < S; s++) dft8_tw<false, false>(x[s], k);
   }
-#pragma unroll
-  for (int s = 0; s < S; s++) dft8<false>(x[s]);
 }
 
 struct NoHook {
@@ -449,50 +544,43 @@ template <int S, typename Hook = NoHook>
 __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lane, const double2* tab, double* sre,
                                                      double* sim, Hook hook = Hook()) {
   const int hi = lane >> 3, lo = lane & 7;
-  double2 w[8];
   hook(0);
 #pragma unroll
   for (int s = 0; s < S; s++) dft8<true>(x[s]);
+  {
+    const Tw8 k = load_tw8<false>(tab + TWS_B + lo, 8);
 #pragma unroll
-  for (int b = 1; b < 8; b++) w[b] = tab[TABV2_TW1 + (b - 1) * 8 + lo];
+    for (int s = 0; s < S; s++) {
 #pragma unroll
-  for (int s = 0; s < S; s++) {
+      for (int q = 0; q < 8; q++) {
+        const int idx = hi * ROW + lo * 8 + (q ^ lo);
+        sre[idx] = x[s][q].x; sim[idx] = x[s][q].y;
+      }
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int idx = hi * ROW + lo * 8 + (q ^ lo);
-      sre[idx] = x[s][q].x; sim[idx] = x[s][q].y;
+      for (int b = 0; b < 8; b++) {
+        const int idx = hi * ROW + b * 8 + (lo ^ b);
+        x[s][b] = make_double2(sre[idx], sim[idx]);
+      }
     }
+    hook(1);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
-      const int idx = hi * ROW + b * 8 + (lo ^ b);
-      x[s][b] = make_double2(sre[idx], sim[idx]);
+    for (int s = 0; s < S; s++) dft8_tw<true, false>(x[s], k);
+  }
+  {
+    const Tw8 k = load_tw8<true>(tab + TWS_C + lane, 64);
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int idx = hi * ROW + q * 8 + lo;
+        sre[idx] = x[s][q].x; sim[idx] = x[s][q].y;
+      }
+#pragma unroll
+      for (int b = 0; b < 8; b++) x[s][b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
     }
-  }
-  hook(1);
+    hook(2);
 #pragma unroll
-  for (int s = 0; s < S; s++) {
-#pragma unroll
-    for (int b = 1; b < 8; b++) x[s][b] = cmul_conj(x[s][b], w[b]);
-    dft8<true>(x[s]);
-  }
-#pragma unroll
-  for (int b = 0; b < 8; b++) w[b] = tab[TABV2_TW0T + b * 64 + lane];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int idx = hi * ROW + q * 8 + lo;
-      sre[idx] = x[s][q].x; sim[idx] = x[s][q].y;
-    }
-#pragma unroll
-    for (int b = 0; b < 8; b++) x[s][b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
-  }
-  hook(2);
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-#pragma unroll
-    for (int b = 0; b < 8; b++) x[s][b] = cmul_conj(x[s][b], w[b]);
-    dft8<true>(x[s]);
+    for (int s = 0; s < S; s++) dft8_tw<true, true>(x[s], k);
   }
 }
 
@@ -513,7 +601,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* slab = smem + TABV2_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
+  char* slab = smem + TWS_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
   T* ct0 = (T*)slab;
   double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
   double* sim = sre + PLANE;
@@ -608,8 +696,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
           const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
           const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0[u & 1][t], own0[u & 1][t], j0 - a_hat);
           const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1[u & 1][t], own1[u & 1][t], j1 - a_hat);
-          // the per-register part of the twist; the per-lane part is in the transform's twiddles
-          x[u >> 1][q] = twist8(make_double2((double)g0, (double)g1), q);
+          x[u >> 1][q] = make_double2((double)g0, (double)g1);   // the twist is in the transform
         }
       };
       issue(0);
@@ -806,7 +893,7 @@ constexpr size_t lat_slab_bytes() {
 // Same products in the same order as the first one-wave schedule, hence the same ciphertext words.
 template <typename T, int K, int L>
 constexpr size_t wavelat_lds_bytes() {
-  return TABV2_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T, K>() + 2 * (size_t)(K + 1) * L * 512 * sizeof(double2);
+  return TWS_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T, K>() + 2 * (size_t)(K + 1) * L * 512 * sizeof(double2);
 }
 
 template <typename T, int K, int L, int BL>
@@ -819,11 +906,11 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = the polynomial this wave owns
-  char* slab = smem + TABV2_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T, K>();
+  char* slab = smem + TWS_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T, K>();
   double* sre = (double*)slab;
   double* sim = sre + PLANE;
   T* stage = (T*)(slab + 2 * PLANE * sizeof(double));
-  double2* spectra = (double2*)(smem + TABV2_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T, K>());  // [2][S][8][64]
+  double2* spectra = (double2*)(smem + TWS_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T, K>());  // [2][S][8][64]
   const uint32_t n = a.n;
   uint32_t image = 0;
 
@@ -882,9 +969,9 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const int32_t d0 = digit_next32<BL, L>(st0[q]), d1 = digit_next32<BL, L>(st1[q]);
-          x[q] = twist8(make_double2((double)d0, (double)d1), q);
+          x[q] = make_double2((double)d0, (double)d1);   // the twist is in the transform
         }
-        fft512_forward<true>(x, lane, tab, sre, sim);
+        fft512_forward_tw(x, lane, tab, sre, sim);
 #pragma unroll
         for (int g = 0; g < 8; g++) img[(((l - 1) * R + wave) * 8 + g) * 64 + lane] = x[g];
       }
@@ -905,7 +992,7 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
           }
         x[g] = v;
       }
-      fft512_inverse<true>(x, lane, tab, sre, sim);
+      fft512_inverse_tw(x, lane, tab, sre, sim);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const double2 v = untwist8(x[q], q);
@@ -1019,11 +1106,38 @@ void wave_fill_tables(uint32_t N, double2* t) {
       const double ang = -2.0 * M_PI * (double)(m * b) / 64.0;
       t[TAB_TW1 + (b - 1) * 8 + m] = make_double2(std::cos(ang), std::sin(ang));
     }
-  for (int b = 0; b < 8; b++)
-    for (int m = 0; m < 64; m++) {
-      const double ang = M_PI * (double)(m * (1 - 4 * b)) / (double)N;
-      t[TAB_TW0T + b * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
+  // folded constants of the twiddled passes (see dft8_tw): th[q] is the angle of input q
+  auto fold = [&](double2* dst, int stride, const double (&th)[8], bool own_w0) {
+    double c[8], tn[8];
+    for (int q = 0; q < 8; q++) {
+      c[q] = std::cos(th[q]);
+      const double sn = std::sin(th[q]);
+      if (std::fabs(c[q]) < 1e-9) c[q] = 0x1.0p-60;   // a quarter turn: finite tangent, value off by 2^-60
+      tn[q] = sn / c[q];
     }
+    dst[0 * stride] = make_double2(tn[1], tn[2]);
+    dst[1 * stride] = make_double2(tn[3], tn[4]);
+    dst[2 * stride] = make_double2(tn[5], tn[6]);
+    dst[3 * stride] = make_double2(tn[7], c[4]);
+    dst[4 * stride] = make_double2(c[5] / c[1], c[6] / c[2]);
+    dst[5 * stride] = make_double2(c[7] / c[3], c[2]);
+    dst[6 * stride] = make_double2(c[3] / c[1], c[1]);
+    dst[7 * stride] = make_double2(c[1] * HALF_SQRT2, 0.0);
+    if (own_w0) dst[8 * stride] = make_double2(std::cos(th[0]), std::sin(th[0]));
+  };
+  for (int lane = 0; lane < 64; lane++) {
+    const int hi = lane >> 3, lo = lane & 7;
+    double th[8];
+    for (int q = 0; q < 8; q++) th[q] = M_PI * (double)((8 * q + lo) * (1 - 4 * hi)) / (double)N;
+    fold(t + TAB_TWS + TWS_A + lane, 64, th, true);
+    for (int b = 0; b < 8; b++) th[b] = M_PI * (double)(lane * (1 - 4 * b)) / (double)N;
+    fold(t + TAB_TWS + TWS_C + lane, 64, th, true);
+  }
+  for (int lo = 0; lo < 8; lo++) {
+    double th[8];
+    for (int q = 0; q < 8; q++) th[q] = -2.0 * M_PI * (double)(lo * q) / 64.0;
+    fold(t + TAB_TWS + TWS_B + lo, 8, th, false);
+  }
 }
 
 template <typename T>
