@@ -732,7 +732,12 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
 #pragma unroll
       for (int c = 0; c < R; c++)
 #pragma unroll
-        for (int g = 0; g < 8; g++) acc[c][g] = make_double2(0.0, 0.0);
+        for (int g = 0; g < 8; g++) {
+          // each zero is written by its own asm statement: as plain constants the compiler clears
+          // the 48 registers ahead of the branch, in every iteration
+          asm volatile("v_mov_b64 %0, 0" : "=v"(acc[c][g].x));
+          asm volatile("v_mov_b64 %0, 0" : "=v"(acc[c][g].y));
+        }
     } else {
       // every key load of this iteration must have landed before the products
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
