@@ -74,6 +74,8 @@ class DeviceServerKey:
         self.n = int(params.lwe_dimension)
         self.big = int(params.glwe_dimension) * int(params.polynomial_size)
         self.glwe_words = (int(params.glwe_dimension) + 1) * int(params.polynomial_size)
+        self.launches = 0      # batch calls made through this object (host or device entry points)
+        self.bootstraps = 0    # ciphertexts in them
 
     # ---- construction ----
     @classmethod
@@ -174,6 +176,8 @@ class DeviceServerKey:
         if a.ndim != 2 or a.shape[1] != in_words:
             raise ValueError(f"expected ciphertexts of {in_words} words, got shape {a.shape}")
         count = a.shape[0]
+        self.launches += 1
+        self.bootstraps += count
         out = np.empty((count, out_words), dtype=self.dtype)
         if with_ids:
             ids = None
@@ -209,6 +213,8 @@ class DeviceServerKey:
 
     def _dev(self, fn, ct_in, lut_ids, ct_out, count, stream, with_ids=True):
         ids_ptr = C.c_void_p(lut_ids.data_ptr()) if lut_ids is not None else None
+        self.launches += 1
+        self.bootstraps += int(count)
         if with_ids:
             check(fn(self._h, C.c_void_p(ct_in.data_ptr()), ids_ptr, C.c_void_p(ct_out.data_ptr()), int(count),
                      C.c_void_p(stream)))

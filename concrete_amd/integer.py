@@ -157,6 +157,12 @@ class ServerKey(CrtServerOps):
     def from_shortint(cls, cks: ClientKey, key: _si.ServerKey) -> "ServerKey":
         return cls(key)
 
+    def gather(self, thunks):
+        """Independent operations side by side, their bootstraps launched together round after
+        round (``shortint.ServerKey.gather``): ``sks.gather([lambda: sks.smart_mul(a, b), lambda:
+        sks.smart_add(c, d)])`` issues what rayon workers calling the reference concurrently would."""
+        return self.key.gather(thunks)
+
     # ------------------------------------------------------------- radix/mod.rs --
     def create_trivial_zero_radix(self, num_blocks: int, like: RadixCiphertext | None = None) -> RadixCiphertext:
         ref = like.blocks[0] if like is not None else None
@@ -165,6 +171,12 @@ class ServerKey(CrtServerOps):
     def _propagate_many(self, pairs) -> None:
         """One propagation step on several (ciphertext, index) pairs whose results do not depend
         on each other: all carry and message extractions in one launch, then the carry adds."""
+        # A block whose degree is below the message modulus has no carry and is its own message:
+        # the step changes nothing in it (the reference bootstraps it all the same, which only
+        # refreshes its noise; every degree check that follows treats it as it treats a fresh
+        # block). Skipping it is what makes an operation on fresh inputs start without a
+        # propagation chain of launches.
+        pairs = [(c, i) for c, i in pairs if c.blocks[i].degree >= self.key.message_modulus]
         carries = []
         with self.key.deferred():
             for ctxt, index in pairs:
@@ -251,7 +263,8 @@ class ServerKey(CrtServerOps):
                 self._full_propagate_many(need)
                 results = [self.unchecked_add(a, b) for a, b in pairs]
             else:
-                results = [op(self, a, b) for a, b in pairs]
+                # independent operations of one level: their bootstraps share launches
+                results = self.gather([lambda a=a, b=b: op(self, a, b) for a, b in pairs])
             seq = seq[:prefix] + results
         return seq[0]
 

@@ -16,6 +16,7 @@ Look-up tables are cached on the device by content, where the reference rebuilds
 from __future__ import annotations
 
 import contextlib
+import threading
 import hashlib
 from dataclasses import dataclass
 from typing import Callable, Iterable, Sequence
@@ -206,6 +207,7 @@ class ServerKey(ShortintOps):
         self._lut_cache: dict[bytes, LookupTable] = {}
         self._device_ids: dict = {}   # (lut id, count) -> device array of ids, reused across calls
         self._queue = None            # bootstraps collected by deferred()
+        self._tls = threading.local()  # .gather: the Gather a worker thread of gather() belongs to
         # engine/mod.rs:195-199: the default accumulator is x -> x % message_modulus
         msg = self.message_modulus
         self._default_acc = self.generate_accumulator(lambda x: x % msg)
@@ -266,12 +268,38 @@ class ServerKey(ShortintOps):
             yield
         finally:
             items, self._queue = self._queue, None
-        self.apply_lookup_table_many(items)
+        self._launch(items)
+
+    def _launch(self, items) -> None:
+        """One launch for ``items`` - or, inside ``gather``, this operation's share of the next
+        combined launch."""
+        if not items:
+            return
+        g = getattr(self._tls, "gather", None)
+        if g is None:
+            self.apply_lookup_table_many(items)
+        else:
+            g.park(items)
+
+    def gather(self, thunks):
+        """Run independent operations side by side and issue the bootstraps each of them needs
+        next as ONE launch, round after round, whatever the operations are (a multiplication next
+        to an addition next to a comparison, of different integers). The reference gets the same
+        concurrency from rayon workers that call the server key at the same time
+        (concrete-integer radix_parallel/mul.rs:319-328, add.rs:14-19); here every operation runs
+        until it needs a bootstrap result, hands its requests over and waits, and when all have
+        done so the requests go to the GPU together. Operations take turns (one runs at a time),
+        so the result is that of calling them one after the other. Returns their results in order.
+        """
+        return _Gather(self, list(thunks)).run()
 
     def keyswitch_programmable_bootstrap_assign(self, ct: Ciphertext, acc: LookupTable) -> None:
         """server_key/mod.rs:219-229 -> engine/server_side/mod.rs:131-155. Degree is not touched."""
         if self._queue is not None:
             self._queue.append((ct, acc))
+            return
+        if getattr(self._tls, "gather", None) is not None:
+            self._launch([(ct, acc)])
             return
         if isinstance(ct.ct, np.ndarray):
             if ct.ct.ndim == 1:
@@ -364,3 +392,64 @@ class ServerKey(ShortintOps):
 
     def keyswitch_bootstrap_batch(self, cts: np.ndarray) -> np.ndarray:
         return self.keyswitch_programmable_bootstrap_batch(cts, self._default_acc)
+
+
+class _Gather:
+    """Cooperative scheduler behind ``ServerKey.gather``: one thread per operation, exactly one of
+    them (or the caller) running at any time. A worker runs until it has bootstraps to launch
+    (``park``) or returns; when every live worker has done either, the caller's thread launches
+    the parked requests together and the round repeats."""
+
+    def __init__(self, key: "ServerKey", thunks):
+        self.key = key
+        self.thunks = thunks
+        self.resume = [threading.Semaphore(0) for _ in thunks]
+        self.arrived = threading.Semaphore(0)
+        self.pending = [None] * len(thunks)
+        self.done = [False] * len(thunks)
+        self.results = [None] * len(thunks)
+        self.errors = [None] * len(thunks)
+
+    def _worker(self, w: int) -> None:
+        self.resume[w].acquire()
+        self.key._tls.gather = self
+        self.key._tls.index = w
+        try:
+            self.results[w] = self.thunks[w]()
+        except BaseException as e:  # re-raised by run() in the caller's thread
+            self.errors[w] = e
+        finally:
+            self.key._tls.gather = None
+            self.done[w] = True
+            self.arrived.release()
+
+    def park(self, items) -> None:
+        w = self.key._tls.index
+        self.pending[w] = list(items)
+        self.arrived.release()
+        self.resume[w].acquire()
+
+    def run(self):
+        threads = [threading.Thread(target=self._worker, args=(w,), daemon=True) for w in range(len(self.thunks))]
+        for t in threads:
+            t.start()
+        live = list(range(len(self.thunks)))
+        while live:
+            for w in live:                 # one at a time: each runs to its next launch point
+                self.resume[w].release()
+                self.arrived.acquire()
+            batch = []
+            for w in live:
+                if self.pending[w]:
+                    batch.extend(self.pending[w])
+                self.pending[w] = None
+            live = [w for w in live if not self.done[w]]
+            if batch:
+                # inside an outer gather this parks in turn; otherwise it is the launch
+                self.key._launch(batch)
+        for t in threads:
+            t.join()
+        for e in self.errors:
+            if e is not None:
+                raise e
+        return self.results

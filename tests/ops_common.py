@@ -270,6 +270,56 @@ def check_radix_ops(cks, sks, count=6, device=False, seed=3, num_blocks=4, tally
         assert icks.decrypt(isks.smart_mul(one, two)) == (201 * 77) % mod
 
 
+def check_gathered_operations(cks, sks, count=5, device=False, seed=9, tally=None):
+    """Different operations on different integers inside ``gather``: same decryptions as one after
+    the other, and as many launches as the longest of them needs, not the sum."""
+    t = tally or Tally()
+    icks = INT.RadixClientKey.__new__(INT.RadixClientKey)
+    icks.key, icks.num_blocks = cks, 4
+    isks = INT.ServerKey(sks)
+    mod = sks.message_modulus ** 4
+    rs = np.random.RandomState(seed)
+    a, b, c, d, e, f = (rs.randint(0, mod, size=count).astype(np.uint64) for _ in range(6))
+    dev = "cuda" if device else None
+    ca, cb, cc, cd, ce, cf = (icks.encrypt_many(v, device=dev) for v in (a, b, c, d, e, f))
+    backend = sks.key
+
+    def carried(x, y):
+        s = isks.unchecked_add(x, y)
+        return isks.unchecked_add(s, y)      # degrees 9: the next smart operation must propagate
+
+    def launches_of(fn):
+        before = backend.launches if hasattr(backend, "launches") else None
+        r = fn()
+        return r, (backend.launches - before if before is not None else None)
+
+    # fresh operands start without a propagation chain: block products + the one sum level that needs carries
+    _, n_mul = launches_of(lambda: isks.smart_mul(ca.clone(), cb.clone()))
+    _, n_add = launches_of(lambda: isks.smart_add(carried(cc, cd), carried(cd, cc)))
+    _, n_xor = launches_of(lambda: isks.smart_bitxor(ce.clone(), cf.clone()))
+    if n_mul is not None:
+        assert n_mul <= 6 and n_xor == 1, (n_mul, n_add, n_xor)
+    (r_mul, r_add, r_xor), n_all = launches_of(lambda: isks.gather([
+        lambda: isks.smart_mul(ca.clone(), cb.clone()),
+        lambda: isks.smart_add(carried(cc, cd), carried(cd, cc)),
+        lambda: isks.smart_bitxor(ce.clone(), cf.clone()),
+    ]))
+    t.eq(icks.decrypt(r_mul), (a * b) % mod)
+    t.eq(icks.decrypt(r_add), (3 * (c + d)) % mod)
+    t.eq(icks.decrypt(r_xor), e ^ f)
+    if n_all is not None:
+        assert n_all == max(n_mul, n_add, n_xor), (n_all, n_mul, n_add, n_xor)
+    # an exception inside one operation surfaces in the caller, the others still complete
+    import pytest
+
+    with pytest.raises(ZeroDivisionError):
+        isks.gather([lambda: 1 // 0, lambda: isks.smart_bitxor(ce.clone(), cf.clone())])
+    # a fresh integer needs no bootstrap to be "propagated"
+    _, n_prop = launches_of(lambda: isks.full_propagate(ca.clone()))
+    if n_prop is not None:
+        assert n_prop == 0
+
+
 def make_basis(message_modulus: int):
     """concrete-integer/src/server_key/crt/tests.rs:25-33."""
     if message_modulus in (2, 3):

@@ -27,6 +27,14 @@ def test_radix_fheuint8(gpu_keys, device):
 
 
 @pytest.mark.parametrize("device", [False, True])
+def test_gathered_operations(gpu_keys, device):
+    """A multiplication, an addition with carries and a bitwise operation of different integers in
+    one ``gather``: launches shared round by round, same decryptions."""
+    cks, sks = gpu_keys
+    OC.check_gathered_operations(cks, sks, count=32, device=device, tally=OC.Tally(per_check=2, total=4))
+
+
+@pytest.mark.parametrize("device", [False, True])
 def test_crt_integers(gpu_keys, device):
     """concrete-integer's CRT representation (basis [2, 3] for 2_2, crt/tests.rs:25-33)."""
     cks, sks = gpu_keys

@@ -31,6 +31,11 @@ def test_radix_layer_on_oracle():
     OC.check_radix_ops(cks, sks, count=5)
 
 
+def test_gathered_operations_share_launches():
+    cks, sks = OC.make_keys()
+    OC.check_gathered_operations(cks, sks)
+
+
 def test_crt_layer_on_oracle():
     cks, sks = OC.make_keys()
     OC.check_crt_ops(cks, sks, count=5)
