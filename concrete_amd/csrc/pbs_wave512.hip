@@ -30,8 +30,23 @@ constexpr int TAB_TWIST = 0;                 // [j] e^{+i pi j / N}, j < 256
 constexpr int TAB_A = 256;                   // [k-1][lane] W_256^(lane k), k = 1..3
 constexpr int TAB_B = TAB_A + 3 * 64;        // [k-1][m]    W_64^(m k),  m < 16
 constexpr int TAB_C = TAB_B + 3 * 16;        // [k-1][m]    W_16^(m k),  m < 4
-constexpr int TAB_AT = TAB_C + 3 * 4;        // [k][lane] e^{i pi lane (1 - 4k) / N}, k = 0..3: TAB_A with the per-lane part of the twist folded in
-constexpr int TAB_COUNT = TAB_AT + 4 * 64;
+constexpr int TAB_COUNT = TAB_C + 3 * 4;      // what the key conversion stages in LDS
+// The bootstrap kernels apply every twiddle on the receiving side of the exchange that follows it,
+// as the input factor of the next radix-4 pass, folded into the butterflies (dft4_tw). Written
+// that way the factor of input j of a pass is e^{i j alpha} with one angle alpha per lane (the part
+// that is common to the four inputs commutes with the pass and joins the next one), so input 0 is
+// never multiplied; the per-lane part of the twist rides along (theta(k) = pi (1 - 4k)/N below).
+// Only the last inverse pass keeps a factor on input 0. Constants per pass and lane, as pairs of
+// doubles: (t1,t2) (t3,c2) (r31,c1) and, for that last pass, w0. With lane = 16 d2 + 4 d1 + d0:
+constexpr int TWS_F1 = 0;                     // [3][d2]       forward pass 2: alpha = 16 theta(d2)
+constexpr int TWS_F2 = TWS_F1 + 3 * 4;        // [3][lane>>2]  forward pass 3: alpha = 4 theta(d2) - pi d1/8
+constexpr int TWS_F3 = TWS_F2 + 3 * 16;       // [3][lane]     forward pass 4: alpha = theta(d2) - 2 pi (4 d0 + d1)/64
+constexpr int TWS_I1 = TWS_F3 + 3 * 64;       // [3][d0]       inverse pass 2: input k carries conj W_16^(d0 k)
+constexpr int TWS_I2 = TWS_I1 + 3 * 4;        // [3][lane&15]  inverse pass 3: conj W_64^((lane & 15) k)
+constexpr int TWS_I3 = TWS_I2 + 3 * 16;       // [4][lane]     inverse pass 4: conj e^{i theta(k) lane}, k = 0..3
+constexpr int TWS_COUNT = TWS_I3 + 4 * 64;    // the bootstrap kernels' LDS image
+constexpr int TAB_TWS = TAB_COUNT;            // where it starts in the table buffer
+constexpr int TAB_TOTAL = TAB_TWS + TWS_COUNT;
 // the per-register part of the twist e^{i pi (64a + lane)/N} = e^{i pi a/8} e^{i pi lane/N}, a = 0..3
 constexpr double TWIST4_RE[4] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173};
 constexpr double TWIST4_IM[4] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
@@ -39,7 +54,7 @@ constexpr int PLANE = 4 * 64;
 template <typename T, int K>
 constexpr size_t slab_bytes() { return (size_t)(K + 1) * N * sizeof(T) + 2 * PLANE * sizeof(double); }
 template <typename T, int K>
-constexpr size_t lds_bytes() { return TAB_COUNT * sizeof(double2) + WAVES * slab_bytes<T, K>(); }
+constexpr size_t lds_bytes() { return TWS_COUNT * sizeof(double2) + WAVES * slab_bytes<T, K>(); }
 
 template <bool INV>
 __device__ __forceinline__ void dft4(double2 (&x)[4]) {
@@ -73,20 +88,16 @@ __device__ __forceinline__ void exchange4(double2 (&x)[S][4], int lane, double* 
   }
 }
 
-// FOLDED: the caller has applied only the per-register part of the twist (TWIST4_*); the per-lane
-// part commutes with the first radix-4 pass and comes with that pass's twiddles (TAB_AT), so no
-// twist table is read, for the same number of multiplications. The inverse mirrors it.
-template <int S, bool FOLDED = false>
+// plain forward transform (twist applied by the caller): the key conversion
+template <int S>
 __device__ __forceinline__ void fft256_forward_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
                                                      double* sim) {
-  double2 w[3], w0;
-  if (FOLDED) w0 = tab[TAB_AT + lane];
+  double2 w[3];
 #pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = FOLDED ? tab[TAB_AT + k * 64 + lane] : tab[TAB_A + (k - 1) * 64 + lane];
+  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_A + (k - 1) * 64 + lane];
 #pragma unroll
   for (int s = 0; s < S; s++) {
     dft4<false>(x[s]);
-    if (FOLDED) x[s][0] = cmul(x[s][0], w0);
 #pragma unroll
     for (int k = 1; k < 4; k++) x[s][k] = cmul(x[s][k], w[k - 1]);
   }
@@ -113,47 +124,117 @@ __device__ __forceinline__ void fft256_forward_multi(double2 (&x)[S][4], int lan
   for (int s = 0; s < S; s++) dft4<false>(x[s]);
 }
 
-template <int S, bool FOLDED = false>
-__device__ __forceinline__ void fft256_inverse_multi(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
-                                                     double* sim) {
-  double2 w[3], w0;
+// ---- radix-4 pass with its input twiddles folded into the butterflies ----
+// A twiddle w = c (1 + i t) times x is c y with y = (x.re - t x.im, x.im + t x.re): two fused
+// multiply-adds. The cosine c is not applied there: the butterfly that combines y_b with its
+// partner y_a computes y_a + (c_b / c_a) y_b, and the factor c_a left on the pair is taken by the
+// second stage in the same way against the chain of input 0, whose factor is 1. The eight
+// additions of the 4-point transform become fused multiply-adds and its three complex
+// multiplications take 6 instructions instead of 12. A twiddle of exactly +-i (c = 0) is stored
+// with c = 2^-60: its tangent is then finite and the value moves by 2^-60 of itself.
+struct Tw4 {
+  double t1, t2, t3;     // tangents of the angles of inputs 1..3
+  double c2, r31, c1;    // cosines: c2, c3 / c1, c1
+  double2 w0;            // twiddle of input 0 (last inverse pass only)
+};
+__device__ __forceinline__ double2 rfma(double s, double2 a, double2 b) {   // s a + b, s real
+  return make_double2(fma(s, a.x, b.x), fma(s, a.y, b.y));
+}
+template <bool INV>
+__device__ __forceinline__ double2 half_twiddle(double2 x, double t) {
+  return INV ? make_double2(fma(t, x.y, x.x), fma(-t, x.x, x.y)) : make_double2(fma(-t, x.y, x.x), fma(t, x.x, x.y));
+}
+// INV: the inputs carry the conjugates of the twiddles and the transform is e^{+2 pi i jk/4}
+template <bool INV, bool X0TW>
+__device__ __forceinline__ void dft4_tw(double2 (&x)[4], const Tw4& k) {
+  const double2 y0 = X0TW ? (INV ? cmul_conj(x[0], k.w0) : cmul(x[0], k.w0)) : x[0];
+  const double2 y1 = half_twiddle<INV>(x[1], k.t1), y2 = half_twiddle<INV>(x[2], k.t2), y3 = half_twiddle<INV>(x[3], k.t3);
+  const double2 s0 = rfma(k.c2, y2, y0), d0 = rfma(-k.c2, y2, y0);
+  const double2 S1 = rfma(k.r31, y3, y1), D1 = rfma(-k.r31, y3, y1);   // pending c1
+  const double2 T = INV ? mul_pos_i(D1) : mul_neg_i(D1);
+  x[0] = rfma(k.c1, S1, s0);
+  x[2] = rfma(-k.c1, S1, s0);
+  x[1] = rfma(k.c1, T, d0);
+  x[3] = rfma(-k.c1, T, d0);
+}
+template <bool X0TW>
+__device__ __forceinline__ Tw4 load_tw4(const double2* p, int stride) {
+  Tw4 k;
+  const double2 p0 = p[0], p1 = p[stride], p2 = p[2 * stride];
+  k.t1 = p0.x; k.t2 = p0.y; k.t3 = p1.x; k.c2 = p1.y; k.r31 = p2.x; k.c1 = p2.y;
+  k.w0 = X0TW ? p[3 * stride] : make_double2(1.0, 0.0);
+  return k;
+}
+// the per-register part of the twist, e^{i pi a/8} on input a of the first forward pass: compile-time constants
+__device__ __forceinline__ Tw4 twist_tw4() {
+  Tw4 k;
+  k.t1 = TWIST4_IM[1] / TWIST4_RE[1]; k.t2 = TWIST4_IM[2] / TWIST4_RE[2]; k.t3 = TWIST4_IM[3] / TWIST4_RE[3];
+  k.c2 = TWIST4_RE[2]; k.r31 = TWIST4_RE[3] / TWIST4_RE[1]; k.c1 = TWIST4_RE[1];
+  k.w0 = make_double2(1.0, 0.0);
+  return k;
+}
+
+// Twisted forward transform of the bootstrap kernels: x[a] = (untwisted) point 64a + lane in, the
+// spectrum of fft256_forward_multi out. `tab` is the kernels' own LDS image (TWS_*).
+template <int S>
+__device__ __forceinline__ void fft256_forward_tw(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
+                                                  double* sim) {
+  {
+    const Tw4 k = twist_tw4();
+#pragma unroll
+    for (int s = 0; s < S; s++) dft4_tw<false, false>(x[s], k);
+  }
+  exchange4<S, 2>(x, lane, sre, sim);
+  {
+    const Tw4 k = load_tw4<false>(tab + TWS_F1 + (lane >> 4), 4);
+#pragma unroll
+    for (int s = 0; s < S; s++) dft4_tw<false, false>(x[s], k);
+  }
+  exchange4<S, 1>(x, lane, sre, sim);
+  {
+    const Tw4 k = load_tw4<false>(tab + TWS_F2 + (lane >> 2), 16);
+#pragma unroll
+    for (int s = 0; s < S; s++) dft4_tw<false, false>(x[s], k);
+  }
+  exchange4<S, 0>(x, lane, sre, sim);
+  {
+    const Tw4 k = load_tw4<false>(tab + TWS_F3 + lane, 64);
+#pragma unroll
+    for (int s = 0; s < S; s++) dft4_tw<false, false>(x[s], k);
+  }
+}
+
+// its unnormalised inverse up to the per-register part of the twist (the caller applies untwist4)
+template <int S>
+__device__ __forceinline__ void fft256_inverse_tw(double2 (&x)[S][4], int lane, const double2* tab, double* sre,
+                                                  double* sim) {
 #pragma unroll
   for (int s = 0; s < S; s++) dft4<true>(x[s]);
   exchange4<S, 0>(x, lane, sre, sim);
+  {
+    const Tw4 k = load_tw4<false>(tab + TWS_I1 + (lane & 3), 4);
 #pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_C + (k - 1) * 4 + (lane & 3)];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-#pragma unroll
-    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
-    dft4<true>(x[s]);
+    for (int s = 0; s < S; s++) dft4_tw<true, false>(x[s], k);
   }
   exchange4<S, 1>(x, lane, sre, sim);
+  {
+    const Tw4 k = load_tw4<false>(tab + TWS_I2 + (lane & 15), 16);
 #pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = tab[TAB_B + (k - 1) * 16 + (lane & 15)];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-#pragma unroll
-    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
-    dft4<true>(x[s]);
+    for (int s = 0; s < S; s++) dft4_tw<true, false>(x[s], k);
   }
   exchange4<S, 2>(x, lane, sre, sim);
-  if (FOLDED) w0 = tab[TAB_AT + lane];
+  {
+    const Tw4 k = load_tw4<true>(tab + TWS_I3 + lane, 64);
 #pragma unroll
-  for (int k = 1; k < 4; k++) w[k - 1] = FOLDED ? tab[TAB_AT + k * 64 + lane] : tab[TAB_A + (k - 1) * 64 + lane];
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-    if (FOLDED) x[s][0] = cmul_conj(x[s][0], w0);
-#pragma unroll
-    for (int k = 1; k < 4; k++) x[s][k] = cmul_conj(x[s][k], w[k - 1]);
-    dft4<true>(x[s]);
+    for (int s = 0; s < S; s++) dft4_tw<true, true>(x[s], k);
   }
-}
-__device__ __forceinline__ double2 twist4(double2 v, int a) {
-  return a == 0 ? v : cmul(v, make_double2(TWIST4_RE[a], TWIST4_IM[a]));
 }
 __device__ __forceinline__ double2 untwist4(double2 v, int a) {
   return a == 0 ? v : cmul_conj(v, make_double2(TWIST4_RE[a], TWIST4_IM[a]));
+}
+// the bootstrap kernels' LDS image of the tables
+__device__ __forceinline__ void stage_tws(double2* tab, const double2* __restrict__ tables, int threads) {
+  for (int t = threadIdx.x; t < TWS_COUNT; t += threads) tab[t] = tables[TAB_TWS + t];
 }
 
 // key conversion: one wave per polynomial, same transform, pre-scaled by 1/256
@@ -201,11 +282,11 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
   constexpr int R = K + 1;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 256) tab[t] = a.tables[t];
+  stage_tws(tab, a.tables, 256);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * slab_bytes<T, K>();
+  char* slab = smem + TWS_COUNT * sizeof(double2) + (size_t)wave * slab_bytes<T, K>();
   T* ct0 = (T*)slab;
   double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
   double* sim = sre + PLANE;
@@ -260,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
             if constexpr (L == 1) {
               const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, p[j0], s0);
               const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, p[j1], s1);
-              x[r][q] = twist4(make_double2((double)g0, (double)g1), q);
+              x[r][q] = make_double2((double)g0, (double)g1);   // the twist is in the transform
             } else {
               const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
               const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
@@ -269,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
               for (int l = L; l >= 1; l--) {
                 const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
-                x[(l - 1) * R + r][q] = twist4(make_double2((double)g0, (double)g1), q);
+                x[(l - 1) * R + r][q] = make_double2((double)g0, (double)g1);
               }
             }
           }
@@ -285,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
                          : "v"(lane_off), "s"(base), "n"(g * 1024 - 2048)
                          : "memory");
         }
-        fft256_forward_multi<S, true>(x, lane, tab, sre, sim);
+        fft256_forward_tw<S>(x, lane, tab, sre, sim);
       }
       double2 acc[R][4];
       if (!work) {
@@ -340,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
           a_cur = wave_uniform(in[i]);
         }
       }
-      fft256_inverse_multi<R, true>(acc, lane, tab, sre, sim);
+      fft256_inverse_tw<R>(acc, lane, tab, sre, sim);
 #pragma unroll
       for (int c = 0; c < R; c++) {
         T* pc = ct0 + c * N;
@@ -376,7 +457,7 @@ template <typename T>
 constexpr size_t lat_slab_bytes() { return (size_t)N * sizeof(T) + 2 * PLANE * sizeof(double); }
 template <typename T, int K, int L>
 constexpr size_t lat_lds_bytes() {
-  return TAB_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T>() + 2 * (size_t)(K + 1) * L * M * sizeof(double2);
+  return TWS_COUNT * sizeof(double2) + (K + 1) * lat_slab_bytes<T>() + 2 * (size_t)(K + 1) * L * M * sizeof(double2);
 }
 
 template <typename T, int K, int L, int BL>
@@ -384,15 +465,15 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
   constexpr int R = K + 1, S = R * L, NS = S * R;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
-  for (int t = threadIdx.x; t < TAB_COUNT; t += 64 * R) tab[t] = a.tables[t];
+  stage_tws(tab, a.tables, 64 * R);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = the polynomial this wave owns
-  char* slab = smem + TAB_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T>();
+  char* slab = smem + TWS_COUNT * sizeof(double2) + (size_t)wave * lat_slab_bytes<T>();
   T* stage = (T*)slab;
   double* sre = (double*)(slab + (size_t)N * sizeof(T));
   double* sim = sre + PLANE;
-  double2* spectra = (double2*)(smem + TAB_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T>());  // [2][S][4][64]
+  double2* spectra = (double2*)(smem + TWS_COUNT * sizeof(double2) + (size_t)R * lat_slab_bytes<T>());  // [2][S][4][64]
   const uint32_t n = a.n;
   uint32_t image = 0;
 
@@ -440,7 +521,7 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
         if constexpr (L == 1) {
           const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, acc[2 * q], s0);
           const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, acc[2 * q + 1], s1);
-          x[0][q] = twist4(make_double2((double)g0, (double)g1), q);
+          x[0][q] = make_double2((double)g0, (double)g1);   // the twist is in the transform
         } else {
           const T r0 = (s0 & N) ? (T)(T(0) - rot0) : rot0;
           const T r1 = (s1 & N) ? (T)(T(0) - rot1) : rot1;
@@ -449,11 +530,11 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
 #pragma unroll
           for (int l = L; l >= 1; l--) {
             const int32_t g0 = next_digit<BL>(st0), g1 = next_digit<BL>(st1);
-            x[l - 1][q] = twist4(make_double2((double)g0, (double)g1), q);
+            x[l - 1][q] = make_double2((double)g0, (double)g1);
           }
         }
       }
-      fft256_forward_multi<L, true>(x, lane, tab, sre, sim);
+      fft256_forward_tw<L>(x, lane, tab, sre, sim);
 
       double2* img = spectra + (size_t)image * (S * M);
 #pragma unroll
@@ -471,7 +552,7 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
         for (int st = 1; st < S; st++) v = cfma(kk[st][g], img[(st * 4 + g) * 64 + lane], v);
         y[0][g] = v;
       }
-      fft256_inverse_multi<1, true>(y, lane, tab, sre, sim);
+      fft256_inverse_tw<1>(y, lane, tab, sre, sim);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const double2 v = untwist4(y[0][q], q);
@@ -520,11 +601,38 @@ inline void fill_tables(double2* t) {
       t[TAB_C + (k - 1) * 4 + m] = make_double2(std::cos(ang), std::sin(ang));
     }
   }
-  for (int k = 0; k < 4; k++)
-    for (int m = 0; m < 64; m++) {
-      const double ang = M_PI * (double)(m * (1 - 4 * k)) / (double)N;
-      t[TAB_AT + k * 64 + m] = make_double2(std::cos(ang), std::sin(ang));
+  // folded constants of the twiddled passes (see dft4_tw): th[j] is the angle of input j
+  auto fold = [&](double2* dst, int stride, const double (&th)[4], bool own_w0) {
+    double c[4], tn[4];
+    for (int j = 0; j < 4; j++) {
+      c[j] = std::cos(th[j]);
+      const double sn = std::sin(th[j]);
+      if (std::fabs(c[j]) < 1e-9) c[j] = 0x1.0p-60;   // a quarter turn: finite tangent, value off by 2^-60
+      tn[j] = sn / c[j];
     }
+    dst[0] = make_double2(tn[1], tn[2]);
+    dst[stride] = make_double2(tn[3], c[2]);
+    dst[2 * stride] = make_double2(c[3] / c[1], c[1]);
+    if (own_w0) dst[3 * stride] = make_double2(std::cos(th[0]), std::sin(th[0]));
+  };
+  auto theta = [](int k) { return M_PI * (double)(1 - 4 * k) / (double)N; };
+  double2* tws = t + TAB_TWS;
+  for (int lane = 0; lane < 64; lane++) {
+    const int d2 = lane >> 4, d1 = (lane >> 2) & 3, d0 = lane & 3;
+    double th[4];
+    for (int j = 0; j < 4; j++) th[j] = j * 16.0 * theta(d2);
+    fold(tws + TWS_F1 + d2, 4, th, false);
+    for (int j = 0; j < 4; j++) th[j] = j * (4.0 * theta(d2) - M_PI * d1 / 8.0);
+    fold(tws + TWS_F2 + (lane >> 2), 16, th, false);
+    for (int j = 0; j < 4; j++) th[j] = j * (theta(d2) - 2.0 * M_PI * (4 * d0 + d1) / 64.0);
+    fold(tws + TWS_F3 + lane, 64, th, false);
+    for (int k = 0; k < 4; k++) th[k] = -2.0 * M_PI * (double)(d0 * k) / 16.0;
+    fold(tws + TWS_I1 + d0, 4, th, false);
+    for (int k = 0; k < 4; k++) th[k] = -2.0 * M_PI * (double)((lane & 15) * k) / 64.0;
+    fold(tws + TWS_I2 + (lane & 15), 16, th, false);
+    for (int k = 0; k < 4; k++) th[k] = theta(k) * lane;
+    fold(tws + TWS_I3 + lane, 64, th, true);
+  }
 }
 
 template <typename T, int K, int L, int BL>
@@ -561,7 +669,7 @@ int launch(const PbsLaunch<T>& a, hipStream_t stream) {
 }  // namespace
 
 bool wave512_supported(const camd_params& p) { return w4::supported(p); }
-size_t wave512_tables_count() { return (size_t)w4::TAB_COUNT; }
+size_t wave512_tables_count() { return (size_t)w4::TAB_TOTAL; }
 void wave512_fill_tables(double2* t) { w4::fill_tables(t); }
 
 template <typename T>
