@@ -230,20 +230,28 @@ __device__ __forceinline__ Tw8 twist_tw8() {
 
 // Twisted forward transform for the bootstrap kernels: x[a] = (untwisted) point 64a + lane in,
 // spectrum out in the order of fft512_forward. `tab` is the kernels' own LDS image (TWS_*).
+// EARLY: the constants of a pass are requested before the exchange in front of it (they do not
+// depend on the data, and a lone stream has nothing else to put under their latency); this costs
+// registers, which the latency kernel has and the first schedule does not.
+template <bool EARLY>
 __device__ __forceinline__ void fft512_forward_tw(double2 (&x)[8], int lane, const double2* tab, double* sre,
                                                   double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
+  Tw8 ka, kb;
+  if (EARLY) ka = load_tw8<true>(tab + TWS_A + lane, 64);
   dft8_tw<false, false>(x, twist_tw8());
 #pragma unroll
   for (int b = 0; b < 8; b++) {
     sre[b * ROW + lane] = x[b].x; sim[b * ROW + lane] = x[b].y;
   }
+  if (EARLY) kb = load_tw8<false>(tab + TWS_B + lo, 8);
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + q * 8 + lo;
     x[q] = make_double2(sre[idx], sim[idx]);
   }
-  dft8_tw<false, true>(x, load_tw8<true>(tab + TWS_A + lane, 64));
+  if (!EARLY) ka = load_tw8<true>(tab + TWS_A + lane, 64);
+  dft8_tw<false, true>(x, ka);
 #pragma unroll
   for (int b = 0; b < 8; b++) {
     const int idx = hi * ROW + b * 8 + (lo ^ b);
@@ -254,26 +262,32 @@ __device__ __forceinline__ void fft512_forward_tw(double2 (&x)[8], int lane, con
     const int idx = hi * ROW + lo * 8 + (q ^ lo);
     x[q] = make_double2(sre[idx], sim[idx]);
   }
-  dft8_tw<false, false>(x, load_tw8<false>(tab + TWS_B + lo, 8));
+  if (!EARLY) kb = load_tw8<false>(tab + TWS_B + lo, 8);
+  dft8_tw<false, false>(x, kb);
 }
 
 // Unnormalised inverse of fft512_forward_tw up to the per-register part of the twist:
 // spectrum in, x[a] = 512 e^{i pi a/16} * point (64a + lane) out (the caller applies untwist8).
+template <bool EARLY>
 __device__ __forceinline__ void fft512_inverse_tw(double2 (&x)[8], int lane, const double2* tab, double* sre,
                                                   double* sim) {
   const int hi = lane >> 3, lo = lane & 7;
+  Tw8 kb, kc;
+  if (EARLY) kb = load_tw8<false>(tab + TWS_B + lo, 8);
   dft8<true>(x);
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + lo * 8 + (q ^ lo);
     sre[idx] = x[q].x; sim[idx] = x[q].y;
   }
+  if (EARLY) kc = load_tw8<true>(tab + TWS_C + lane, 64);
 #pragma unroll
   for (int b = 0; b < 8; b++) {
     const int idx = hi * ROW + b * 8 + (lo ^ b);
     x[b] = make_double2(sre[idx], sim[idx]);
   }
-  dft8_tw<true, false>(x, load_tw8<false>(tab + TWS_B + lo, 8));
+  if (!EARLY) kb = load_tw8<false>(tab + TWS_B + lo, 8);
+  dft8_tw<true, false>(x, kb);
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int idx = hi * ROW + q * 8 + lo;
@@ -281,7 +295,8 @@ __device__ __forceinline__ void fft512_inverse_tw(double2 (&x)[8], int lane, con
   }
 #pragma unroll
   for (int b = 0; b < 8; b++) x[b] = make_double2(sre[b * ROW + lane], sim[b * ROW + lane]);
-  dft8_tw<true, true>(x, load_tw8<true>(tab + TWS_C + lane, 64));
+  if (!EARLY) kc = load_tw8<true>(tab + TWS_C + lane, 64);
+  dft8_tw<true, true>(x, kc);
 }
 // the inverse of the per-register part of the twist (a is a compile-time index at every call site)
 __device__ __forceinline__ double2 untwist8(double2 v, int a) {
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
           const int32_t g0 = digit_next32<BL, L>(st0[q]), g1 = digit_next32<BL, L>(st1[q]);
           x[q] = make_double2((double)g0, (double)g1);   // the twist is in the transform
         }
-        fft512_forward_tw(x, lane, tab, sre, sim);
+        fft512_forward_tw<false>(x, lane, tab, sre, sim);
 #pragma unroll
         for (int c = 0; c <= K; c++) {
 #pragma unroll
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel(PbsLaunch<T> a) {
           z[g] = acc[c][g];
           acc[c][g] = make_double2(0.0, 0.0);
         }
-        fft512_inverse_tw(z, lane, tab, sre, sim);
+        fft512_inverse_tw<false>(z, lane, tab, sre, sim);
         T* pc = ct0 + c * N;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -976,7 +991,7 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
           const int32_t d0 = digit_next32<BL, L>(st0[q]), d1 = digit_next32<BL, L>(st1[q]);
           x[q] = make_double2((double)d0, (double)d1);   // the twist is in the transform
         }
-        fft512_forward_tw(x, lane, tab, sre, sim);
+        fft512_forward_tw<true>(x, lane, tab, sre, sim);
 #pragma unroll
         for (int g = 0; g < 8; g++) img[(((l - 1) * R + wave) * 8 + g) * 64 + lane] = x[g];
       }
@@ -997,7 +1012,7 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
           }
         x[g] = v;
       }
-      fft512_inverse_tw(x, lane, tab, sre, sim);
+      fft512_inverse_tw<true>(x, lane, tab, sre, sim);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const double2 v = untwist8(x[q], q);
