@@ -42,6 +42,7 @@ __device__ __forceinline__ uint32_t checked_lut_id(const PbsLaunch<T>& a, size_t
 
 // ---- rendezvous of persistent waves that share an L2 (bootstrap kernels) ----
 constexpr uint32_t WAVE_QUORUM_SLACK = 8;
+constexpr uint32_t WAVE_QUORUM_GRACE = 128;   // polls (about 0.5 us each) granted to the stragglers once the quorum is there
 constexpr int SYNC_GROUPS = 16;         // the hardware's XCC id is a 4-bit field (MI355X has 8 XCDs)
 constexpr int SYNC_STRIDE = 32;         // counters 128 bytes apart
 constexpr size_t RENDEZVOUS_BYTES = 2 * (size_t)SYNC_GROUPS * SYNC_STRIDE * sizeof(uint32_t);
@@ -49,8 +50,12 @@ constexpr size_t RENDEZVOUS_BYTES = 2 * (size_t)SYNC_GROUPS * SYNC_STRIDE * size
 // Rendezvous of the persistent waves that share an L2. Nothing is assumed about how workgroups are
 // dealt to XCDs or how many XCDs there are: every wave reads the id of the XCD it runs on from the
 // hardware register, enrols in that XCD's member count when it starts, and between ciphertexts
-// reports to that XCD's arrival counter and waits until all but 1/WAVE_QUORUM_SLACK of the members
-// have arrived. The first wait comes a whole bootstrap (milliseconds) after the launch, when every
+// reports to that XCD's arrival counter and waits for all members; once all but
+// 1/WAVE_QUORUM_SLACK of them are there, the rest get a short grace period and are then left
+// behind. Waiting for the quorum alone let waves that are a fraction of a percent slower fall
+// further behind with every ciphertext until they streamed the key through the L2 on their own
+// (measured on the N = 512 instance: four times the fetch traffic after 32 ciphertexts); waiting
+// for every wave without a bound would tie the kernel to its slowest one. The first wait comes a whole bootstrap (milliseconds) after the launch, when every
 // workgroup of the device-sized grid has long enrolled; should a member count still be short, or a
 // wave lag, the wait is bounded and only cache behaviour is affected, never results.
 // Both counter arrays live in the key's scratch buffer and are cleared by every launch.
@@ -69,9 +74,12 @@ struct XcdRendezvous {
     if (lane == 0) {
       __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t m = __hip_atomic_load(members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t target = (round + 1) * m - m / WAVE_QUORUM_SLACK;
+      const uint32_t all = (round + 1) * m, quorum = all - m / WAVE_QUORUM_SLACK;
+      uint32_t grace = WAVE_QUORUM_GRACE;
       for (uint32_t spin = 0; spin < (1u << 16); spin++) {
-        if (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        const uint32_t seen = __hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= all) break;
+        if (seen >= quorum && grace-- == 0) break;
         __builtin_amdgcn_s_sleep(16);
       }
     }
