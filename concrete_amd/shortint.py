@@ -409,6 +409,7 @@ class _Gather:
         self.done = [False] * len(thunks)
         self.results = [None] * len(thunks)
         self.errors = [None] * len(thunks)
+        self.failure = None               # exception of a combined launch, handed to every parked operation
 
     def _worker(self, w: int) -> None:
         self.resume[w].acquire()
@@ -428,6 +429,8 @@ class _Gather:
         self.pending[w] = list(items)
         self.arrived.release()
         self.resume[w].acquire()
+        if self.failure is not None:       # the combined launch failed: unwind this operation too
+            raise self.failure
 
     def run(self):
         threads = [threading.Thread(target=self._worker, args=(w,), daemon=True) for w in range(len(self.thunks))]
@@ -446,9 +449,14 @@ class _Gather:
             live = [w for w in live if not self.done[w]]
             if batch:
                 # inside an outer gather this parks in turn; otherwise it is the launch
-                self.key._launch(batch)
+                try:
+                    self.key._launch(batch)
+                except BaseException as e:
+                    self.failure = e
         for t in threads:
             t.join()
+        if self.failure is not None:
+            raise self.failure
         for e in self.errors:
             if e is not None:
                 raise e

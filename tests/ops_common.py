@@ -314,6 +314,20 @@ def check_gathered_operations(cks, sks, count=5, device=False, seed=9, tally=Non
 
     with pytest.raises(ZeroDivisionError):
         isks.gather([lambda: 1 // 0, lambda: isks.smart_bitxor(ce.clone(), cf.clone())])
+    # a launch that fails (here: the backend raises) unwinds every gathered operation and surfaces once
+    real = backend.ks_pbs if not device else backend.ks_pbs_device
+
+    def broken(*args, **kwargs):
+        raise RuntimeError("launch failed")
+
+    name = "ks_pbs_device" if device else "ks_pbs"
+    setattr(backend, name, broken)
+    try:
+        with pytest.raises(RuntimeError, match="launch failed"):
+            isks.gather([lambda: isks.smart_bitxor(ce.clone(), cf.clone()), lambda: isks.smart_bitand(ce.clone(), cf.clone())])
+    finally:
+        setattr(backend, name, real)
+    t.eq(icks.decrypt(isks.smart_bitand(ce.clone(), cf.clone())), e & f)
     # a fresh integer needs no bootstrap to be "propagated"
     _, n_prop = launches_of(lambda: isks.full_propagate(ca.clone()))
     if n_prop is not None:
