@@ -211,6 +211,26 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+_JSON_OUT = None
+
+
+def claim_stdout() -> None:
+    """The JSON line is the only thing this process writes to its standard output: keep a private
+    copy of descriptor 1 for it and send everything else that is written there (gloo prints its rank
+    connections on it) to standard error."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line: dict) -> None:
+    out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def spawn_ranks(args, argv) -> int:
     """Start `args.gpus` ranks of this script under torch.distributed.run and wait for them. Runs in
     a process that has made no GPU call; rank 0's JSON line reaches stdout through the inherited
@@ -255,7 +275,7 @@ def plumbing(args) -> None:
     owned = rk.sum_over_ranks(hi - lo)
     agree = rk.sum_over_ranks(int(checksum == int(torch.arange(blob_bytes, dtype=torch.int64).to(torch.uint8).to(torch.int64).sum())))
     if rk.rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "bootstraps/sec (node), MESSAGE_2_CARRY_2", "value": None, "unit": "bootstraps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "none",
@@ -263,7 +283,7 @@ def plumbing(args) -> None:
             "config": {"workload": "rank plumbing only (PARAM_MESSAGE_2_CARRY_2 shards), no kernels",
                        "batch_per_gpu": count, "global_batch": owned},
             "ranks_with_identical_key_blob": agree, "key_broadcast_ms": key_broadcast_ms,
-            "barrier_region_ms": elapsed * 1e3}), flush=True)
+            "barrier_region_ms": elapsed * 1e3})
     rk.close()
 
 
@@ -317,7 +337,7 @@ def other_workload(args) -> None:
     if rank == 0:
         fpp = flop_per_pbs(p)
         achieved = count * fpp / (tm["pbs_ms"] * 1e-3) / 1e12 if tm["pbs_ms"] > 0 else 0.0
-        print(json.dumps({
+        emit({
             "metric": f"bootstraps/sec (node), {pname}", "value": count * world * args.steps / elapsed,
             "unit": "bootstraps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -330,7 +350,7 @@ def other_workload(args) -> None:
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flop_per_bootstrap": fpp,
                          "kernel_ms": tm["pbs_ms"], "keyswitch_kernel_ms": tm["ks_ms"],
                          "note": "peak is the vendor's FP64 vector figure; the guide of this image has no FP64 row"},
-            "cpu_baseline": None}), flush=True)
+            "cpu_baseline": None})
     rk.close()
 
 
@@ -359,6 +379,7 @@ def main() -> None:
             raise SystemExit(spawn_ranks(args, sys.argv[1:]))
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={os.environ['WORLD_SIZE']} of the launcher")
+    claim_stdout()
     if args.plumbing:
         return plumbing(args)
     if args.workload != "2_2":
@@ -543,7 +564,7 @@ def main() -> None:
                 line["failing_indices_rank0"] = [int(i) for i in idx[:16]]
             line["failures_on_rank0"] = wrong_here
             line["failures_shared_with_cpu"] = shared if wrong_here else 0
-        print(json.dumps(line), flush=True)
+        emit(line)
 
     rk.close()
 

@@ -45,5 +45,18 @@ def add_chain():
 
 
 timed("smart_add (operands with full carries -> 2 propagations)", add_chain, (6 * ((x + 2 * y) % 256) // 3) % 256 * 0 + (2 * (x + 2 * y)) % 256)
-timed("smart_mul", lambda: sks.smart_mul(cx.clone(), cy.clone()), (x * y) % 256)
+timed("smart_mul (fresh operands)", lambda: sks.smart_mul(cx.clone(), cy.clone()), (x * y) % 256)
+
+
+def mul_carried():
+    # both operands hold carries in every block: the whole propagation chain runs first
+    a = sks.unchecked_add(sks.unchecked_add(cx, cy), cy)
+    b = sks.unchecked_add(sks.unchecked_add(cy, cx), cx)
+    return sks.smart_mul(a, b)
+
+
+timed("smart_mul (operands with full carries)", mul_carried, ((x + 2 * y) * (y + 2 * x)) % 256)
+timed("gather(smart_mul, smart_add with carries, smart_bitxor)",
+      lambda: sks.gather([lambda: sks.smart_mul(cx.clone(), cy.clone()), add_chain,
+                          lambda: sks.smart_bitxor(cx.clone(), cy.clone())])[0], (x * y) % 256)
 timed("smart_bitxor", lambda: sks.smart_bitxor(cx.clone(), cy.clone()), x ^ y)
