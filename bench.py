@@ -2,7 +2,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): concrete-shortint PARAM_MESSAGE_2_CARRY_2, batch 2^14 fresh
+Workload (the configuration the headline metric is quoted on): concrete-shortint PARAM_MESSAGE_2_CARRY_2, batch 2^14 fresh
 ciphertexts per GPU, already resident in HBM. One "step" is one KS+PBS pass over the batch.
 With N > 1 every rank owns its own batch of 2^14 (weak scaling); the server key is built on
 rank 0 and broadcast once over RCCL; there is no collective in the timed region.

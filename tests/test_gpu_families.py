@@ -95,7 +95,7 @@ def test_boolean_pbs_ks_bit_exact(gpu_ctx, params, variant):
 
 
 def test_full_size_boolean_nand_truth_table(gpu_ctx):
-    """BASELINE configs[0] on the GPU: NAND at DEFAULT_PARAMETERS with the full n = 586, on the
+    """The single-gate benchmark configuration on the GPU: NAND at DEFAULT_PARAMETERS with the full n = 586, on the
     bit-exact kernel (asked for explicitly; the default for this set is the wave kernel, next test but one)."""
     p = P.DEFAULT_PARAMETERS
     ks = get_keys(p, 32)

@@ -1,5 +1,5 @@
 """Operation layer on the GPU, full PARAM_MESSAGE_2_CARRY_2 keys: the shortint operations and
-FheUint8-shaped radix integers (4 blocks of 2 bits, BASELINE configs[4]) driven through the C ABI,
+FheUint8-shaped radix integers (4 blocks of 2 bits, the FheUint8 benchmark configuration) driven through the C ABI,
 on host batches and on device-resident batches (linear part: camd_lwe_axpby_device)."""
 import numpy as np
 import pytest

@@ -223,7 +223,7 @@ def test_reference_properties_2_2(keys_2_2):
 
 
 def test_boolean_nand_reference_path():
-    """BASELINE configs[0]: one NAND at DEFAULT_PARAMETERS on the CPU path
+    """The single-gate benchmark configuration: one NAND at DEFAULT_PARAMETERS on the CPU path
     (engine/mod.rs:364-405: -a - b + 1/8, then bootstrap, then keyswitch)."""
     p = P.DEFAULT_PARAMETERS
     ks = get_keys(p, 32)
