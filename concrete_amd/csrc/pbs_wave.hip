@@ -894,6 +894,176 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   }
 }
 
+// ---- the bootstrap, row-step schedule (several decomposition levels) ----
+// The second schedule for a GGSW of more than one level: a step is one row r of the rotated
+// difference. Its L digit polynomials are transformed interleaved (as the k+1 rows are above), the
+// L (k+1) key polynomials of that row wait in accumulation registers (requested during the step
+// before), and the Fourier sums of the k+1 columns stay in registers across the k+1 steps of a
+// CMUX; after the last row they are transformed back, interleaved, and rounded into the
+// accumulator. Persistent waves with the per-XCD rendezvous, as above. Products are accumulated
+// rows outermost, levels from the finest up: the order of the first schedule and of the k+1-wave
+// variant, hence the same ciphertext words.
+template <typename T, int K, int L, int BL>
+__global__ __launch_bounds__(256, 1) void wave_pbs_kernel_rows(PbsLaunch<T> a) {
+  constexpr int N = 1024, M = 512, LOGN = 10, R = K + 1;
+  constexpr int NS = L * R;   // key polynomials of a step: [level][column], all parked
+  static_assert(NS * 32 <= 224, "a step's key rows must fit the accumulation registers");
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  stage_folded_tables(tab, a.tables, 256);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* slab = smem + TWS_COUNT * sizeof(double2) + (size_t)wave * wave_slab_bytes<T, K>();
+  T* ct0 = (T*)slab;
+  double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
+  double* sim = sre + PLANE;
+
+  XcdRendezvous rendezvous;
+  if (a.scratch) rendezvous.enrol(a.scratch, lane);
+  const size_t per_round = (size_t)gridDim.x * WAVES;
+  uint32_t round = 0;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round, round++) {
+    const T* in = a.ct_in + ct * a.in_stride;
+    const uint32_t n = a.n;
+    const uint32_t lut_id = checked_lut_id(a, ct);
+    const T* lut = a.luts + (size_t)lut_id * (R * N);
+    {
+      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+      for (int idx = lane; idx < R * N; idx += 64) {
+        const int c = idx >> LOGN, j = idx & (N - 1);
+        ct0[idx] = rotated_coeff<T>(lut + (size_t)c * N, j, d0, N);
+      }
+    }
+    // first iteration whose mask element is not zero (the reference skips the others)
+    uint32_t i = 0;
+    T a_cur = wave_uniform(in[0]);
+    while (i < n && a_cur == 0) {
+      i++;
+      a_cur = wave_uniform(in[i]);  // in[n] is the body: readable
+    }
+
+    v4u bqa[NS][8];
+#pragma unroll
+    for (int sl = 0; sl < NS; sl++)
+#pragma unroll
+      for (int g = 0; g < 8; g++) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(bqa[sl][g].x));
+
+    double2 acc[R][8];
+#pragma unroll
+    for (int c = 0; c < R; c++)
+#pragma unroll
+      for (int g = 0; g < 8; g++) acc[c][g] = make_double2(0.0, 0.0);
+
+    // The loop body runs once as a pure "load" pass (work = false) so that the key loads have a
+    // single site; afterwards every pass transforms step (cur, r) and loads the step after it.
+    bool work = false;
+    uint32_t a_hat = 0, cur = 0;
+    int r = 0;
+    for (;;) {
+      if (work) {
+        double2 x[L][8];
+        {
+          const T* p = ct0 + r * N;
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
+            const T x0 = rotated_coeff<T>(p, j0, a_hat, N) - p[j0];
+            const T x1 = rotated_coeff<T>(p, j1, a_hat, N) - p[j1];
+            uint32_t st0 = digit_state32<T, BL, L>(x0), st1 = digit_state32<T, BL, L>(x1);
+#pragma unroll
+            for (int l = L; l >= 1; l--) {
+              const int32_t g0 = digit_next32<BL, L>(st0), g1 = digit_next32<BL, L>(st1);
+              x[l - 1][q] = make_double2((double)g0, (double)g1);   // the twist is in the transform
+            }
+          }
+        }
+        fft512_forward_multi<L>(x, lane, tab, sre, sim);
+        // every key load of this step must have landed before the products
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++)
+          asm volatile("" : "+a"(bqa[sl][0]), "+a"(bqa[sl][1]), "+a"(bqa[sl][2]), "+a"(bqa[sl][3]),
+                            "+a"(bqa[sl][4]), "+a"(bqa[sl][5]), "+a"(bqa[sl][6]), "+a"(bqa[sl][7]));
+#pragma unroll
+        for (int c = 0; c < R; c++)
+#pragma unroll
+          for (int g = 0; g < 8; g++) {
+            double2 v = acc[c][g];
+#pragma unroll
+            for (int l = L; l >= 1; l--) v = cfma(as_double2(bqa[(l - 1) * R + c][g]), x[l - 1][g], v);
+            acc[c][g] = v;
+          }
+      }
+
+      // the step after this one: the next row of the same iteration, or row 0 of the next
+      // iteration whose mask element is not zero
+      const bool last_row = !work || r == K;
+      const bool more = last_row ? (i < n) : true;
+      const uint32_t next_it = last_row ? i : cur;
+      const int next_r = last_row ? 0 : r + 1;
+      const uint32_t next_hat = last_row ? (modswitch<T>(a_cur, LOGN) & (2 * N - 1)) : a_hat;
+      if (more) {
+        // [it][level][row][col] polynomials of M complex values; scalar base in the middle of each
+        const char* row0 = (const char*)(a.fbsk + (((size_t)next_it * L * R + (size_t)next_r) * R) * M) + 4096;
+#pragma unroll
+        for (int l = 1; l <= L; l++)
+#pragma unroll
+          for (int c = 0; c < R; c++) {
+            const char* base = row0 + ((size_t)(l - 1) * R * R + c) * (M * sizeof(double2));
+#pragma unroll
+            for (int g = 0; g < 8; g++)
+              asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                           : "=a"(bqa[(l - 1) * R + c][g])
+                           : "v"(lane_off), "s"(base), "n"(g * 1024 - 4096)
+                           : "memory");
+          }
+      }
+      if (last_row && more) {   // scan ahead for the iteration after that one
+        i++;
+        a_cur = wave_uniform(in[i]);
+        while (i < n && a_cur == 0) {
+          i++;
+          a_cur = wave_uniform(in[i]);
+        }
+      }
+
+      if (work && r == K) {
+        fft512_inverse_multi<R>(acc, lane, tab, sre, sim);
+#pragma unroll
+        for (int c = 0; c < R; c++) {
+          T* pc = ct0 + c * N;
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const uint32_t j0 = 64 * q + lane;
+            const double2 v = untwist8(acc[c][q], q);
+            pc[j0] = torus_accumulate(pc[j0], v.x);
+            pc[j0 + M] = torus_accumulate(pc[j0 + M], v.y);
+            acc[c][q] = make_double2(0.0, 0.0);
+          }
+        }
+      }
+      if (!more) break;
+      work = true;
+      cur = next_it;
+      r = next_r;
+      a_hat = next_hat;
+    }
+
+    T* out = a.ct_out + ct * a.out_stride;
+    for (int idx = lane; idx < K * N; idx += 64) {
+      const int c = idx >> LOGN, j = idx & (N - 1);
+      const T* p = ct0 + c * N;
+      out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
+    }
+    if (lane == 0) out[K * N] = ct0[K * N];
+    if ((size_t)(round + 1) * per_round < a.count) rendezvous.arrive_and_wait(round, lane);
+  }
+}
+
 // per-wave LDS of the k+1-wave variant: exchange image + one staging row for the rotation
 template <typename T, int K>
 constexpr size_t lat_slab_bytes() {
@@ -1075,6 +1245,23 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
         CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
       }
       hipLaunchKernelGGL(kern2, dim3(persistent), dim3(256), lds, stream, a);
+      CAMD_HIP(hipGetLastError());
+      return CAMD_OK;
+    }
+  }
+  if constexpr (L > 1) {
+    if (schedule == 2) {
+      auto kernr = wave_pbs_kernel_rows<T, K, L, BL>;
+      CAMD_HIP(hipFuncSetAttribute((const void*)kernr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int dev = 0, cus = 0;
+      CAMD_HIP(hipGetDevice(&dev));
+      CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;
+      if (persistent < grid) {
+        if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
+        CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
+      }
+      hipLaunchKernelGGL(kernr, dim3(persistent), dim3(256), lds, stream, a);
       CAMD_HIP(hipGetLastError());
       return CAMD_OK;
     }

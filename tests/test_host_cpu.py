@@ -261,6 +261,30 @@ def test_wave_kernel_keeps_parked_key_registers_untouched(tmp_path):
     assert sorted(loads) == list(range(0, parked, 4))       # one load site per parked quad
 
 
+def test_row_step_wave_kernel_keeps_parked_key_registers_untouched(tmp_path):
+    """The same invariant for the row-step schedule of the multi-level N = 1024 instance
+    (three levels, k = 1: six key polynomials of a step in a0..a191)."""
+    import re
+    import subprocess
+
+    src = os.path.join(ROOT, "concrete_amd", "csrc", "pbs_wave.hip")
+    out = tmp_path / "pbs_wave.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src,
+                    "-o", str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    labels = [m.start() for m in re.finditer(r"^_ZN\S*wave_pbs_kernel_rows\S*:", text, re.M)]
+    assert len(labels) == 1
+    body = text[text.index(":", labels[0]):text.index("s_endpgm", labels[0])]
+    assert "scratch_" not in body and "v_accvgpr_mov_b32" not in body
+    parked = 192
+    writes = [int(m.group(1)) for m in re.finditer(r"v_accvgpr_write_b32 a(\d+),", body)]
+    assert sorted(w for w in writes if w < parked) == list(range(0, parked, 4))
+    for m in re.finditer(r"ds_read\w* a\[(\d+):", body):
+        assert int(m.group(1)) >= parked
+    loads = [int(m.group(1)) for m in re.finditer(r"global_load_dwordx4 a\[(\d+):", body)]
+    assert sorted(loads) == list(range(0, parked, 4))
+
+
 def test_wave512_kernel_keeps_parked_key_registers_untouched(tmp_path):
     """The same invariant for the N = 512 instance: 14 key slabs of 4 register quads (a0..a223)."""
     import re
