@@ -309,6 +309,16 @@ def check_gathered_operations(cks, sks, count=5, device=False, seed=9, tally=Non
     t.eq(icks.decrypt(r_xor), e ^ f)
     if n_all is not None:
         assert n_all == max(n_mul, n_add, n_xor), (n_all, n_mul, n_add, n_xor)
+    # gathers nest: an operation that gathers its own parts joins the rounds of the outer gather
+    (n_mul2, n_xor2), n_nested = launches_of(lambda: isks.gather([
+        lambda: isks.gather([lambda: isks.smart_mul(ca.clone(), cb.clone()), lambda: isks.smart_mul(cb.clone(), ca.clone())]),
+        lambda: isks.smart_bitxor(ce.clone(), cf.clone()),
+    ]))
+    t.eq(icks.decrypt(n_mul2[0]), (a * b) % mod)
+    t.eq(icks.decrypt(n_mul2[1]), (a * b) % mod)
+    t.eq(icks.decrypt(n_xor2), e ^ f)
+    if n_nested is not None:
+        assert n_nested == n_mul, (n_nested, n_mul)
     # an exception inside one operation surfaces in the caller, the others still complete
     import pytest
 
