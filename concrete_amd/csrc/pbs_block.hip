@@ -175,10 +175,19 @@ __device__ __forceinline__ void exchange(double2 (&x)[1 << PL], double2* buf, ui
                                          uint32_t lo_to) {
   constexpr int P = 1 << PL;
   const uint32_t key = lo_from < lo_to ? lo_from : lo_to;
-  __syncthreads();  // every load of the previous exchange has completed
+  // The exchange transposes the register index with the PL thread-index bits just below the larger
+  // `lo`. When those are lane bits (larger lo <= 6) the eight threads that trade values sit in one
+  // wave, every wave reads back exactly the slots it wrote, those are the slots it read in the
+  // exchange before, and no other wave touches them (enumerated for every size: the XOR swizzle
+  // moves a value inside its aligned 16-slot block only, and a wave owns whole blocks). LDS
+  // operations of a wave execute in order, so such an exchange needs no workgroup barrier at all:
+  // two of the four exchanges of a transform at N = 16384, two of three at N = 2048..8192, all of
+  // them up to N = 1024.
+  const bool crosses_waves = (lo_from > lo_to ? lo_from : lo_to) > 6u;
+  if (crosses_waves) __syncthreads();  // every load of the previous exchange has completed
 #pragma unroll
   for (int r = 0; r < P; r++) buf[Blk<PL>::slot(Blk<PL>::elem(r, t, lo_from), key)] = x[r];
-  __syncthreads();
+  if (crosses_waves) __syncthreads();
 #pragma unroll
   for (int r = 0; r < P; r++) x[r] = buf[Blk<PL>::slot(Blk<PL>::elem(r, t, lo_to), key)];
 }
