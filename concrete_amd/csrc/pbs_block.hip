@@ -343,6 +343,9 @@ void block_pbs_kernel(PbsLaunch<T> a) {
   const double inv_m = 1.0 / (double)M;
   // the decomposed field and its rounding bit lie in the upper dword (all 64-bit sets do)
   const bool high_dword = sizeof(T) == 8 && bl * L <= 31u;
+  // the state left after the first digit has base_log (levels - 1) + 1 bits: when that is at most
+  // 16 (two levels of up to 15 bits) the two states of a point share one parked word
+  const bool pack16 = high_dword && L > 1 && bl * (L - 1u) + 1u <= 16u;
 
   for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
     const T* in = a.ct_in + ct * a.in_stride;
@@ -421,8 +424,12 @@ void block_pbs_kernel(PbsLaunch<T> a) {
                     uint32_t st0 = block_state32(h0, bl, L), st1 = block_state32(h1, bl, L);
                     g0 = block_next32(st0, bl);
                     g1 = block_next32(st1, bl);
-                    gst<uint32_t>(str, ((uint32_t)(2 * q) * Tn + t) * 4u, st0);
-                    gst<uint32_t>(str, ((uint32_t)(2 * q + 1) * Tn + t) * 4u, st1);
+                    if (pack16) {
+                      gst<uint32_t>(str, ((uint32_t)q * Tn + t) * 4u, st0 | (st1 << 16));
+                    } else {
+                      gst<uint32_t>(str, ((uint32_t)(2 * q) * Tn + t) * 4u, st0);
+                      gst<uint32_t>(str, ((uint32_t)(2 * q + 1) * Tn + t) * 4u, st1);
+                    }
                   }
                   x[q] = cmul(make_double2((double)g0, (double)g1), tw[u]);
                 } else {
@@ -446,8 +453,13 @@ void block_pbs_kernel(PbsLaunch<T> a) {
               double2 tw[GS];
 #pragma unroll
               for (int u = 0; u < GS; u++) {
-                sa[u] = gld<uint32_t>(str, ((uint32_t)(2 * (q0 + u)) * Tn + t) * 4u);
-                sb[u] = gld<uint32_t>(str, ((uint32_t)(2 * (q0 + u) + 1) * Tn + t) * 4u);
+                if (pack16) {
+                  sa[u] = gld<uint32_t>(str, ((uint32_t)(q0 + u) * Tn + t) * 4u);
+                  sb[u] = 0;
+                } else {
+                  sa[u] = gld<uint32_t>(str, ((uint32_t)(2 * (q0 + u)) * Tn + t) * 4u);
+                  sb[u] = gld<uint32_t>(str, ((uint32_t)(2 * (q0 + u) + 1) * Tn + t) * 4u);
+                }
                 tw[u] = gld<double2>(twist, ((uint32_t)(q0 + u) * Tn + t) * (uint32_t)sizeof(double2));
               }
               __builtin_amdgcn_sched_barrier(0);
@@ -455,7 +467,7 @@ void block_pbs_kernel(PbsLaunch<T> a) {
               for (int u = 0; u < GS; u++) {
                 const int q = q0 + u;
                 // the parked state never exceeds 32 bits (base_log * (level - 1) + 1 bits)
-                uint32_t st0 = sa[u], st1 = sb[u];
+                uint32_t st0 = pack16 ? (sa[u] & 0xFFFFu) : sa[u], st1 = pack16 ? (sa[u] >> 16) : sb[u];
                 const int32_t g0 = block_next32(st0, bl);
                 const int32_t g1 = block_next32(st1, bl);
                 if constexpr (L > 2) {  // with two levels the state is spent after this digit
