@@ -354,6 +354,62 @@ def other_workload(args) -> None:
     rk.close()
 
 
+def fheuint8_workload(args) -> None:
+    """FheUint8 (four blocks of PARAM_MESSAGE_2_CARRY_2) multiplications on device-resident batches
+    through the radix layer of concrete_amd.integer: one step = one smart_mul of `batch` independent
+    pairs per GPU (real keys; every product is decrypted and compared after the timed region)."""
+    from concrete_amd import integer as INT
+
+    rk = Ranks(args)
+    world, rank = rk.world, rk.rank
+    p = P.PARAM_MESSAGE_2_CARRY_2
+    pairs = args.batch if args.batch != 1 << 14 else 1024
+    ctx = Context(rk.device_index)
+    cks = INT.RadixClientKey(p, 4, seed=SEED)          # fixed test seed: the same keys on every rank
+    sks = INT.ServerKey.new(cks, ctx=ctx, variant=args.variant)
+    rs = np.random.RandomState(1 + rank)
+    x = rs.randint(0, 256, size=pairs).astype(np.uint64)
+    y = rs.randint(0, 256, size=pairs).astype(np.uint64)
+    cx, cy = cks.encrypt_many(x, device=rk.device), cks.encrypt_many(y, device=rk.device)
+    dk = sks.key.key
+
+    def step():
+        return sks.smart_mul(cx.clone(), cy.clone())
+
+    for _ in range(max(args.warmup, 1)):   # the first call uploads the look-up tables
+        step()
+    rk.barrier_sync()
+    dk.timing_enable(True)
+    l0, b0 = dk.launches, dk.bootstraps
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prod = step()
+    rk.barrier_sync()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0)
+    tm = dk.timing_read()
+    dk.timing_enable(False)
+    wrong = rk.sum_over_ranks(int(np.count_nonzero(cks.decrypt(prod) != (x * y) % 256)))
+    if rank == 0:
+        launches = (dk.launches - l0) / args.steps
+        bootstraps = (dk.bootstraps - b0) / args.steps
+        emit({
+            "metric": "FheUint8 multiplications/sec (node), radix of 4 x MESSAGE_2_CARRY_2",
+            "value": pairs * world * args.steps / elapsed, "unit": "multiplications/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"concrete-integer smart_mul of {pairs} independent FheUint8 pairs per GPU "
+                                   "(fresh operands, device-resident), carry-propagation and block-product "
+                                   "bootstraps batched per dependency level",
+                       "pairs_per_gpu": pairs, "launches_per_multiplication_batch": launches,
+                       "bootstraps_per_multiplication": bootstraps / pairs},
+            "roofline": {"bound": "valu_fp64", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                         "traffic": None, "kernel_ms_per_launch": tm["pbs_ms"], "keyswitch_kernel_ms_per_launch": tm["ks_ms"],
+                         "note": "the bootstrap kernel of the headline workload at the batch of one dependency level"},
+            "cpu_baseline": None, "wrong_products": wrong,
+            "expected_wrong_products": pairs * world * bootstraps / pairs * 2.0 ** -13.9})
+    rk.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,7 +423,7 @@ def main() -> None:
     ap.add_argument("--luts", type=int, default=1, help="number of distinct look-up tables spread over the batch")
     ap.add_argument("--plumbing", action="store_true",
                     help="rank plumbing only, on the CPU with gloo: no GPU and no kernels (value is null)")
-    ap.add_argument("--workload", default="2_2", choices=sorted(OTHER_WORKLOADS) + ["2_2"],
+    ap.add_argument("--workload", default="2_2", choices=sorted(OTHER_WORKLOADS) + ["2_2", "fheuint8"],
                     help="2_2 (default) is the headline configuration; the others time further configurations of the "
                          "same path with random key material (timing does not depend on the data)")
     args = ap.parse_args()
@@ -382,6 +438,8 @@ def main() -> None:
     claim_stdout()
     if args.plumbing:
         return plumbing(args)
+    if args.workload == "fheuint8":
+        return fheuint8_workload(args)
     if args.workload != "2_2":
         return other_workload(args)
 
