@@ -484,15 +484,30 @@ int run_op_host(camd_server_key* key, Op op, const void* in, const uint32_t* d_i
   camd_context* ctx = key->ctx;
   const size_t iw = in_words(key, op) * key->word, ow = out_words(key, op) * key->word;
   const size_t chunk = host_chunk();
-  // a short tail is folded into the slice before it
-  const size_t slices = count / 2 < chunk ? 1 : count / chunk;
+  // Slice boundaries. The copy of the first slice in and of the last slice out have nothing to
+  // hide behind, so for a batch of at least four slices those two are half a slice; a short tail
+  // is folded into the slice before it.
+  std::vector<size_t> bounds{0};
+  if (count / 2 < chunk) {
+    bounds.push_back(count);
+  } else if (count >= 4 * chunk && chunk >= 2) {
+    bounds.push_back(chunk / 2);
+    while (count - bounds.back() >= chunk + chunk / 2 + chunk / 2) bounds.push_back(bounds.back() + chunk);
+    // what is left is between one and two slices: the last half slice takes the end of it
+    if (count - bounds.back() > chunk / 2) bounds.push_back(count - chunk / 2);
+    bounds.push_back(count);
+  } else {
+    for (size_t i = 1; i < count / chunk; i++) bounds.push_back(i * chunk);
+    bounds.push_back(count);
+  }
+  const size_t slices = bounds.size() - 1;
   EventList events;
   hipEvent_t computed_prev = nullptr;
   size_t prev_first = 0, prev_n = 0;
   int rc = CAMD_OK;
   hipError_t e = hipSuccess;
   for (size_t i = 0; i < slices && rc == CAMD_OK && e == hipSuccess; i++) {
-    const size_t first = i * chunk, n = (i + 1 == slices) ? count - first : chunk;
+    const size_t first = bounds[i], n = bounds[i + 1] - bounds[i];
     hipEvent_t arrived = nullptr, computed = nullptr;
     e = events.add(&arrived);
     if (e == hipSuccess) e = events.add(&computed);

@@ -251,6 +251,10 @@ def test_host_buffer_batch_is_sliced_without_changing_results(gpu_ctx, keys_2_2,
     monkeypatch.setenv("CAMD_HOST_CHUNK", "0")       # one slice
     single = dk.ks_pbs(cts, lut_ids)
     assert np.array_equal(sliced, whole) and np.array_equal(single, whole)
+    monkeypatch.setenv("CAMD_HOST_CHUNK", "12")      # four slices and more: half slices at both ends (6, 12, 12, 17, 6)
+    assert np.array_equal(dk.ks_pbs(cts, lut_ids), whole)
+    monkeypatch.setenv("CAMD_HOST_CHUNK", "13")      # 6, 13, 13, 15, 6
+    assert np.array_equal(dk.ks_pbs(cts, lut_ids), whole)
     monkeypatch.setenv("CAMD_HOST_CHUNK", "16")
     assert np.array_equal(dk.ks(cts), np.stack([ks.o.keyswitch(ks.ksk, c) for c in cts]))
 
