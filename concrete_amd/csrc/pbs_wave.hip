@@ -1121,15 +1121,11 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
       }
     }
 
-    T a_next = wave_uniform(in[0]);
-    for (uint32_t i = 0; i < n; i++) {
-      const T a_cur = a_next;
-      a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
-      if (a_cur == 0) continue;           // the reference skips these too; every wave of the group sees the same value
-      const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
-
-      // column `wave` of key row i: stream (level l, row r) at index (l - 1) R + r
-      const double2* key = a.fbsk + (size_t)i * NS * M + (size_t)wave * M + lane;
+    // One CMUX: column `wave` of key row `it` (stream (level l, row r) at index (l - 1) R + r) is
+    // requested first and flies behind the rotation and the forward transform.
+    auto cmux = [&](uint32_t it, T a_val) {
+      const uint32_t a_hat = modswitch<T>(a_val, LOGN) & (2 * N - 1);
+      const double2* key = a.fbsk + (size_t)it * NS * M + (size_t)wave * M + lane;
       double2 kk[S][8];
 #pragma unroll
       for (int st = 0; st < S; st++)
@@ -1188,6 +1184,38 @@ __global__ __launch_bounds__(64 * (K + 1)) void wave_pbs_kernel_lat(PbsLaunch<T>
         const double2 v = untwist8(x[q], q);
         acc[2 * q] = torus_accumulate(acc[2 * q], v.x);
         acc[2 * q + 1] = torus_accumulate(acc[2 * q + 1], v.y);
+      }
+    };
+    // Iterations whose mask element is zero are skipped, as the reference does; every wave of the
+    // group sees the same values. The two loop forms compile to different schedules, and each
+    // instance takes the one that measured faster (single level: 2.8 against 3.1 ms per 2_2
+    // bootstrap; three levels: 4.2 against 5.3 ms per gate).
+    if constexpr (L == 1) {
+      T a_next = wave_uniform(in[0]);
+      for (uint32_t i = 0; i < n; i++) {
+        const T a_cur = a_next;
+        a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
+        if (a_cur == 0) continue;
+        cmux(i, a_cur);
+      }
+    } else {
+      uint32_t i = 0;
+      T a_cur = wave_uniform(in[0]);
+      while (i < n && a_cur == 0) {
+        i++;
+        a_cur = wave_uniform(in[i]);
+      }
+      while (i < n) {
+        const T a_peek = in[i + 1];   // requested before the CMUX, looked at after it
+        cmux(i, a_cur);
+        uint32_t j = i + 1;
+        T a_nx = wave_uniform(a_peek);
+        while (j < n && a_nx == 0) {
+          j++;
+          a_nx = wave_uniform(in[j]);
+        }
+        i = j;
+        a_cur = a_nx;
       }
     }
 
