@@ -463,6 +463,10 @@ constexpr size_t lat_lds_bytes() {
 template <typename T, int K, int L, int BL>
 __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
   constexpr int R = K + 1, S = R * L, NS = S * R;
+#ifndef W4_LOOP_PEEK
+#define W4_LOOP_PEEK (L > 1)
+#endif
+  constexpr bool LOOP_PEEK = W4_LOOP_PEEK;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
   stage_tws(tab, a.tables, 64 * R);
@@ -492,11 +496,7 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
         acc[2 * q + 1] = rotated_coeff<T>(lut, 64 * q + lane + M, d0, N);
       }
     }
-    T a_next = wave_uniform(in[0]);
-    for (uint32_t i = 0; i < n; i++) {
-      const T a_cur = a_next;
-      a_next = wave_uniform(in[i + 1]);  // in[n] is the body: readable
-      if (a_cur == 0) continue;           // skipped by every wave of the group alike
+    auto cmux = [&](uint32_t i, T a_cur) {
       const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
 
       // column `wave` of key row i, every stream
@@ -558,6 +558,36 @@ __global__ __launch_bounds__(64 * (K + 1)) void pbs_kernel_lat(PbsLaunch<T> a) {
         const double2 v = untwist4(y[0][q], q);
         acc[2 * q] = torus_accumulate(acc[2 * q], v.x);
         acc[2 * q + 1] = torus_accumulate(acc[2 * q + 1], v.y);
+      }
+    };
+    // Iterations whose mask element is zero are skipped (by every wave of the group alike). Two
+    // loop forms, as in the N = 1024 variant: each instance takes the one that measured faster.
+    if constexpr (LOOP_PEEK) {
+      uint32_t i = 0;
+      T a_cur = wave_uniform(in[0]);
+      while (i < n && a_cur == 0) {
+        i++;
+        a_cur = wave_uniform(in[i]);  // in[n] is the body: readable
+      }
+      while (i < n) {
+        const T a_peek = in[i + 1];   // requested before the CMUX, looked at after it
+        cmux(i, a_cur);
+        uint32_t j = i + 1;
+        T a_nx = wave_uniform(a_peek);
+        while (j < n && a_nx == 0) {
+          j++;
+          a_nx = wave_uniform(in[j]);
+        }
+        i = j;
+        a_cur = a_nx;
+      }
+    } else {
+      T a_next = wave_uniform(in[0]);
+      for (uint32_t i = 0; i < n; i++) {
+        const T a_cur = a_next;
+        a_next = wave_uniform(in[i + 1]);
+        if (a_cur == 0) continue;
+        cmux(i, a_cur);
       }
     }
 
