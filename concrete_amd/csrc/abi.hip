@@ -249,7 +249,8 @@ int key_fill(camd_server_key* key, const void* bsk_host, const void* ksk_host) {
   if (rc == CAMD_OK) {
     if (key->variant == CAMD_PBS_WAVE) rc = wave_bsk_to_fourier<T>((const T*)d_std, (double2*)key->blob, key->tables, p, s);
     else if (key->variant == CAMD_PBS_BLOCK)
-      rc = block_bsk_to_fourier<T>((const T*)d_std, (double2*)key->blob, key->tables, p.polynomial_size, polys, s);
+      rc = block_bsk_to_fourier<T>((const T*)d_std, (double2*)key->blob, key->tables, p.polynomial_size, polys,
+                                   p.pbs_level, s);
     else rc = generic_bsk_to_fourier<T>((const T*)d_std, (double2*)key->blob, key->tables, p.polynomial_size, polys, s);
   }
   if (rc == CAMD_OK) {

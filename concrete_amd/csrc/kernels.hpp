@@ -130,7 +130,7 @@ bool block_supported(const camd_params& p);
 size_t block_scratch_bytes(const camd_params& p, unsigned* grid_out, size_t count);
 template <typename T>
 int block_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, uint32_t N, size_t polys,
-                         hipStream_t stream);
+                         uint32_t levels, hipStream_t stream);
 template <typename T>
 int block_launch_pbs(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream);
 

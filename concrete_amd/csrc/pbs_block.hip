@@ -97,6 +97,8 @@ __device__ __forceinline__ int32_t block_next32(uint32_t& state, uint32_t bl) {
   return (int32_t)(res - (carry << bl));
 }
 
+constexpr int pass_lo(int B, int PL, int q) { return B - (q + 1) * PL > 0 ? B - (q + 1) * PL : 0; }
+
 template <int PL>
 struct Blk {
   static constexpr int P = 1 << PL;
@@ -213,35 +215,185 @@ constexpr int group_points(int want, int P) {
 // 64-bit sets of the same sizes the loss of resident workgroups costs more than the traffic saved.
 constexpr bool block_acc_in_lds(int torus_bytes, int B) { return torus_bytes == 4 && B <= 9; }
 
-constexpr int pass_lo(int B, int PL, int q) { return B - (q + 1) * PL > 0 ? B - (q + 1) * PL : 0; }
 
-// in: x[r] = element r*T + t (natural order). out: x[r] = position (t << PL) | r of the
-// bit-reversed spectrum. Pass q keeps index bits [lo_q, lo_q + PL) in registers.
-template <int B, int PL>
-__device__ __forceinline__ void block_fft_forward(double2 (&x)[1 << PL], double2* buf, const double2* ltw,
-                                                  const double2* __restrict__ gtw, uint32_t t) {
-  constexpr int Q = (B + PL - 1) / PL;
-  // the thread index is made opaque so that the many per-pass addresses are recomputed here
-  // (a few integer operations) instead of being hoisted out of the CMUX loop into registers
-  asm volatile("" : "+v"(t));
+// ---- exchanges that trade lane bits only: register shuffles instead of an LDS round trip ----
+// Transposing one register-index bit with one lane bit moves half of the values to the lane whose
+// number differs in that bit. Lane bits 5 and 4 have an instruction for exactly that
+// (v_permlane32_swap / v_permlane16_swap, one per register pair); bits 3 and 2 take two row shifts
+// whose bank mask writes only the lanes that receive. Bits 1 and 0 have no cheap form and stay in LDS.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_into(uint32_t old, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, BANK_MASK, false);
+}
+template <int PB>
+__device__ __forceinline__ void swap_words(uint32_t& a, uint32_t& b) {
+  static_assert(PB >= 2 && PB <= 5, "lane bit without a cheap transposition");
+  if constexpr (PB == 5) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+  } else if constexpr (PB == 4) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+  } else if constexpr (PB == 3) {   // row_shr:8 into lanes 8..15, row_shl:8 into lanes 0..7
+    const uint32_t na = dpp_into<0x118, 0xC>(a, b);
+    b = dpp_into<0x108, 0x3>(b, a);
+    a = na;
+  } else {                          // row_shr:4 into banks 1 and 3, row_shl:4 into banks 0 and 2
+    const uint32_t na = dpp_into<0x114, 0xA>(a, b);
+    b = dpp_into<0x104, 0x5>(b, a);
+    a = na;
+  }
+}
+template <int PB>
+__device__ __forceinline__ void swap_complex(double2& a, double2& b) {
+  uint32_t a0 = (uint32_t)__double2loint(a.x), a1 = (uint32_t)__double2hiint(a.x);
+  uint32_t a2 = (uint32_t)__double2loint(a.y), a3 = (uint32_t)__double2hiint(a.y);
+  uint32_t b0 = (uint32_t)__double2loint(b.x), b1 = (uint32_t)__double2hiint(b.x);
+  uint32_t b2 = (uint32_t)__double2loint(b.y), b3 = (uint32_t)__double2hiint(b.y);
+  swap_words<PB>(a0, b0); swap_words<PB>(a1, b1); swap_words<PB>(a2, b2); swap_words<PB>(a3, b3);
+  a = make_double2(__hiloint2double((int)a1, (int)a0), __hiloint2double((int)a3, (int)a2));
+  b = make_double2(__hiloint2double((int)b1, (int)b0), __hiloint2double((int)b3, (int)b2));
+}
+// value (register bit S = rho, lane bit PB = lambda) moves to (register bit S = lambda, lane bit PB = rho)
+template <int PL, int S, int PB>
+__device__ __forceinline__ void transpose_bit(double2 (&x)[1 << PL]) {
 #pragma unroll
-  for (int q = 0; q < Q; q++) {
-    if (q > 0) exchange<PL>(x, buf, t, pass_lo(B, PL, q - 1), pass_lo(B, PL, q));
-    forward_stages<PL>(x, pass_lo(B, PL, q), B - 1 - q * PL, B, t, q == 0, gtw, ltw);
+  for (int r = 0; r < (1 << PL); r++)
+    if (!(r & (1 << S))) swap_complex<PB>(x[r], x[r | (1 << S)]);
+}
+// The exchange between the passes with in-register bits [LO_FROM, LO_FROM + PL) and [LO_TO, LO_TO + PL),
+// LO_FROM > LO_TO, for threads whose index bit b sits on physical lane bit b + SHIFT: the top
+// D = LO_FROM - LO_TO register bits trade places with thread bits [LO_TO, LO_FROM), then the
+// registers are renamed so that the new low bits come first.
+template <int PL, int LO_FROM, int LO_TO, int SHIFT, bool INVERSE>
+__device__ __forceinline__ void shuffle_exchange(double2 (&x)[1 << PL]) {
+  constexpr int D = LO_FROM - LO_TO, P = 1 << PL;
+  static_assert(D >= 1 && D <= 3 && D <= PL, "unsupported exchange width");
+  if constexpr (INVERSE && D < PL) {
+    double2 y[P];
+#pragma unroll
+    for (int rn = 0; rn < P; rn++) y[((rn & ((1 << D) - 1)) << (PL - D)) | (rn >> D)] = x[rn];
+#pragma unroll
+    for (int r = 0; r < P; r++) x[r] = y[r];
+  }
+  if constexpr (D >= 1) transpose_bit<PL, PL - D + 0, LO_TO + 0 + SHIFT>(x);
+  if constexpr (D >= 2) transpose_bit<PL, PL - D + 1, LO_TO + 1 + SHIFT>(x);
+  if constexpr (D >= 3) transpose_bit<PL, PL - D + 2, LO_TO + 2 + SHIFT>(x);
+  if constexpr (!INVERSE && D < PL) {
+    double2 y[P];
+#pragma unroll
+    for (int rn = 0; rn < P; rn++) y[rn] = x[((rn & ((1 << D) - 1)) << (PL - D)) | (rn >> D)];
+#pragma unroll
+    for (int r = 0; r < P; r++) x[r] = y[r];
   }
 }
 
+// Instances whose transforms use the shuffles (measured per instance against the LDS form, same
+// results bit for bit): N = 16384 with two levels +6 %, N = 2048 +2 %, N = 256 +4..7 %; N = 512,
+// 4096 and 8192 within 1 % either way, N = 1024 and N = 16384 with three levels 2-3 % slower.
+constexpr bool block_shuffles(int torus_bytes, int B, int levels) {
+  return torus_bytes == 8 && (B == 7 || B == 10 || (B == 13 && levels <= 2));
+}
+
+// How the exchanges of a transform are carried out. `rot_pass`: from this pass on (-1: never) a
+// thread works under the lane number rotated right by two bits, so that its index bits 0..3 sit on
+// physical lane bits 2..5, the ones with a cheap transposition; the last exchange that crosses
+// waves (through LDS in any case) hands the values over to the rotated numbering.
+constexpr int plan_rot_pass(int B, int PL, bool shuf) {
+  if (!shuf) return -1;
+  const int Q = (B + PL - 1) / PL;
+  for (int q = 1; q < Q; q++)
+    if (pass_lo(B, PL, q - 1) <= 6) return (q >= 2 && pass_lo(B, PL, q - 1) == 4) ? q - 1 : -1;
+  return -1;
+}
+// lane-bit offset of exchange q (between passes q-1 and q) when it is done by shuffles, -1 for LDS
+constexpr int plan_shift(int B, int PL, int q, bool shuf) {
+  if (!shuf) return -1;
+  const int rot = plan_rot_pass(B, PL, shuf);
+  const int from = pass_lo(B, PL, q - 1), to = pass_lo(B, PL, q);
+  if (rot >= 0 && q > rot) return 2;
+  if (from <= 6 && to >= 2) return 0;
+  return -1;
+}
+__device__ __forceinline__ uint32_t rotated_lane_index(uint32_t t) {
+  return (t & ~63u) | ((t & 63u) >> 2) | ((t & 3u) << 4);
+}
+// The exchange that hands over to (or back from) the rotated numbering: the in-register bits on
+// the rotated side start at bit 4, and there physical lane bits 0, 1 carry element bits 4 + PL and
+// 5 + PL while lane bits 2..5 carry element bits 0..3. A 16-byte LDS load serves sixteen lanes per
+// cycle from all 64 banks; a 16-byte store serves eight consecutive lanes per cycle into one half
+// of the banks, so their eight slots must agree in slot bit 3 (measured: a store whose eight lanes
+// straddle both halves takes twice as long). Handing over (natural stores, rotated loads) folds
+// the two element bits into slot bits 2, 3; handing back (rotated stores, natural loads) into
+// slot bits 1, 2. Both are free of bank conflicts on both sides.
+template <int PL, bool BACK>
+__device__ __forceinline__ uint32_t rot_slot(uint32_t i) { return i ^ (((i >> (4 + PL)) & 3u) << (BACK ? 1 : 2)); }
+template <int PL, bool BACK>
+__device__ __forceinline__ void exchange_renumbering(double2 (&x)[1 << PL], double2* buf, uint32_t t_from,
+                                                     uint32_t t_to, uint32_t lo_from, uint32_t lo_to) {
+  constexpr int P = 1 << PL;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < P; r++) buf[rot_slot<PL, BACK>(Blk<PL>::elem(r, t_from, lo_from))] = x[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < P; r++) x[r] = buf[rot_slot<PL, BACK>(Blk<PL>::elem(r, t_to, lo_to))];
+}
+
+template <int B, int PL, bool SHUF, int QI>
+__device__ __forceinline__ void forward_pass_chain(double2 (&x)[1 << PL], double2* buf, const double2* ltw,
+                                                   const double2* __restrict__ gtw, uint32_t t, uint32_t tr) {
+  constexpr int Q = (B + PL - 1) / PL;
+  if constexpr (QI < Q) {
+    constexpr int rot = plan_rot_pass(B, PL, SHUF);
+    if constexpr (QI > 0) {
+      constexpr int from = pass_lo(B, PL, QI - 1), to = pass_lo(B, PL, QI);
+      constexpr int shift = plan_shift(B, PL, QI, SHUF);
+      if constexpr (shift >= 0) shuffle_exchange<PL, from, to, shift, false>(x);
+      else if constexpr (QI == rot) exchange_renumbering<PL, false>(x, buf, t, tr, from, to);
+      else exchange<PL>(x, buf, t, from, to);
+    }
+    forward_stages<PL>(x, pass_lo(B, PL, QI), B - 1 - QI * PL, B, (rot >= 0 && QI >= rot) ? tr : t, QI == 0, gtw, ltw);
+    forward_pass_chain<B, PL, SHUF, QI + 1>(x, buf, ltw, gtw, t, tr);
+  }
+}
+template <int B, int PL, bool SHUF, int QI>
+__device__ __forceinline__ void inverse_pass_chain(double2 (&x)[1 << PL], double2* buf, const double2* ltw,
+                                                   const double2* __restrict__ gtw, uint32_t t, uint32_t tr) {
+  if constexpr (QI >= 0) {
+    constexpr int rot = plan_rot_pass(B, PL, SHUF);
+    inverse_stages<PL>(x, pass_lo(B, PL, QI), B - 1 - QI * PL, B, (rot >= 0 && QI >= rot) ? tr : t, QI == 0, gtw, ltw);
+    if constexpr (QI > 0) {
+      constexpr int from = pass_lo(B, PL, QI - 1), to = pass_lo(B, PL, QI);   // as the forward exchange names them
+      constexpr int shift = plan_shift(B, PL, QI, SHUF);
+      if constexpr (shift >= 0) shuffle_exchange<PL, from, to, shift, true>(x);
+      else if constexpr (QI == rot) exchange_renumbering<PL, true>(x, buf, tr, t, to, from);
+      else exchange<PL>(x, buf, t, to, from);
+    }
+    inverse_pass_chain<B, PL, SHUF, QI - 1>(x, buf, ltw, gtw, t, tr);
+  }
+}
+
+// in: x[r] = element r*T + t (natural order). out: x[r] = position (t' << PL) | r of the
+// bit-reversed spectrum, t' = t or, for the instances that renumber their lanes, rotated_lane_index(t):
+// the key conversion, the multiply-accumulate and the inverse transform of an instance agree on it.
+// Pass q keeps index bits [lo_q, lo_q + PL) in registers.
+template <int B, int PL, bool SHUF>
+__device__ __forceinline__ void block_fft_forward(double2 (&x)[1 << PL], double2* buf, const double2* ltw,
+                                                  const double2* __restrict__ gtw, uint32_t t) {
+  // the thread index is made opaque so that the many per-pass addresses are recomputed here
+  // (a few integer operations) instead of being hoisted out of the CMUX loop into registers
+  asm volatile("" : "+v"(t));
+  forward_pass_chain<B, PL, SHUF, 0>(x, buf, ltw, gtw, t, rotated_lane_index(t));
+}
+
 // exact mirror of block_fft_forward: same passes in reverse order
-template <int B, int PL>
+template <int B, int PL, bool SHUF>
 __device__ __forceinline__ void block_fft_inverse(double2 (&x)[1 << PL], double2* buf, const double2* ltw,
                                                   const double2* __restrict__ gtw, uint32_t t) {
   constexpr int Q = (B + PL - 1) / PL;
   asm volatile("" : "+v"(t));
-#pragma unroll
-  for (int q = Q - 1; q >= 0; q--) {
-    inverse_stages<PL>(x, pass_lo(B, PL, q), B - 1 - q * PL, B, t, q == 0, gtw, ltw);
-    if (q > 0) exchange<PL>(x, buf, t, pass_lo(B, PL, q), pass_lo(B, PL, q - 1));
-  }
+  inverse_pass_chain<B, PL, SHUF, Q - 1>(x, buf, ltw, gtw, t, rotated_lane_index(t));
 }
 
 // per-stage compact copy of the stage twiddles of every pass but the first: stage b at [2^b - 1, 2^(b+1) - 1)
@@ -254,7 +406,7 @@ __device__ __forceinline__ void fill_lds_twiddles(double2* ltw, const double2* _
   }
 }
 
-template <typename T, int B, int PL>
+template <typename T, int B, int PL, bool SHUF>
 __global__ __launch_bounds__(1 << (B - PL)) void block_bsk_fourier_kernel(const T* __restrict__ bsk,
                                                                           double2* __restrict__ out,
                                                                           const double2* __restrict__ tables) {
@@ -278,7 +430,7 @@ __global__ __launch_bounds__(1 << (B - PL)) void block_bsk_fourier_kernel(const 
     const double im = signed_to_double((S)poly[j + M]) * scale;
     x[r] = cmul(make_double2(re, im), twist[j]);
   }
-  block_fft_forward<B, PL>(x, buf, ltw, gtw, t);
+  block_fft_forward<B, PL, SHUF>(x, buf, ltw, gtw, t);
   double2* dst = out + (size_t)blockIdx.x * M;
 #pragma unroll
   for (int r = 0; r < P; r++) dst[(uint32_t)r * Tn + t] = x[r];
@@ -304,6 +456,7 @@ void block_pbs_kernel(PbsLaunch<T> a) {
   constexpr uint32_t G = KP1 * N;
   constexpr uint32_t logN = B + 1;
   constexpr int CREG = block_reg_columns(B, KP1);
+  constexpr bool SHUF = block_shuffles((int)sizeof(T), B, LV);
   // points handled between two scheduling fences in the load-heavy phases: bounds the registers
   // the compiler may spend on loads in flight
   // points per load group of each phase: what fits the registers left next to the Fourier sums
@@ -481,7 +634,7 @@ void block_pbs_kernel(PbsLaunch<T> a) {
           }
           STAMP(tG)
           const double2* rows = a.fbsk + ((((size_t)i * L + (l - 1)) * KP1 + r) * KP1) * M;
-          block_fft_forward<B, PL>(x, buf, ltw, gtw, t);
+          block_fft_forward<B, PL, SHUF>(x, buf, ltw, gtw, t);
           STAMP(tF)
           asm volatile("" : "+v"(t));
           if (l == L && r == 0) {
@@ -536,7 +689,7 @@ void block_pbs_kernel(PbsLaunch<T> a) {
         for (int q = 0; q < P; q++)
           x[q] = (c < CREG) ? accf[c < CREG ? c : 0][q] : gld<double2>(accg, ((uint32_t)(c - CREG) * M + (uint32_t)q * Tn + t) * 16u);
         STAMP(tM)
-        block_fft_inverse<B, PL>(x, buf, ltw, gtw, t);
+        block_fft_inverse<B, PL, SHUF>(x, buf, ltw, gtw, t);
         STAMP(tI)
         asm volatile("" : "+v"(t));
         T* p = ct0 + (size_t)c * N;
@@ -613,16 +766,24 @@ int block_launch_instance(const PbsLaunch<T>& a, unsigned grid, hipStream_t stre
   return fail(CAMD_EINVAL, "the register-blocked kernel has no instance for this level count");
 }
 
-template <typename T, int B, int PL>
-int block_fourier_instance(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream) {
+template <typename T, int B, int PL, bool SHUF>
+int block_fourier_layout(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream) {
   const size_t lds = block_lds_bytes(2u << B, 0, 8, 1);  // the conversion kernel keeps nothing but the image in LDS
   if (lds > 64 * 1024)
-    CAMD_HIP(hipFuncSetAttribute((const void*)block_bsk_fourier_kernel<T, B, PL>,
+    CAMD_HIP(hipFuncSetAttribute((const void*)block_bsk_fourier_kernel<T, B, PL, SHUF>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((block_bsk_fourier_kernel<T, B, PL>), dim3((unsigned)polys), dim3(1u << (B - PL)), lds, stream,
-                     bsk_std, fbsk, tables);
+  hipLaunchKernelGGL((block_bsk_fourier_kernel<T, B, PL, SHUF>), dim3((unsigned)polys), dim3(1u << (B - PL)), lds,
+                     stream, bsk_std, fbsk, tables);
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;
+}
+// the spectrum order of the key is the one the bootstrap instance for this level count works in
+template <typename T, int B, int PL>
+int block_fourier_instance(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, uint32_t levels,
+                           hipStream_t stream) {
+  if (block_shuffles((int)sizeof(T), B, (int)levels))
+    return block_fourier_layout<T, B, PL, true>(bsk_std, fbsk, tables, polys, stream);
+  return block_fourier_layout<T, B, PL, false>(bsk_std, fbsk, tables, polys, stream);
 }
 
 }  // namespace
@@ -665,15 +826,15 @@ size_t block_scratch_bytes(const camd_params& p, unsigned* grid_out, size_t coun
 
 template <typename T>
 int block_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, uint32_t N, size_t polys,
-                         hipStream_t stream) {
+                         uint32_t levels, hipStream_t stream) {
   switch (N) {
-    case 256: return block_fourier_instance<T, 7, 1>(bsk_std, fbsk, tables, polys, stream);
-    case 512: return block_fourier_instance<T, 8, 2>(bsk_std, fbsk, tables, polys, stream);
-    case 1024: return block_fourier_instance<T, 9, 3>(bsk_std, fbsk, tables, polys, stream);
-    case 2048: return block_fourier_instance<T, 10, 3>(bsk_std, fbsk, tables, polys, stream);
-    case 4096: return block_fourier_instance<T, 11, 3>(bsk_std, fbsk, tables, polys, stream);
-    case 8192: return block_fourier_instance<T, 12, BLOCK_BIG_PL>(bsk_std, fbsk, tables, polys, stream);
-    case 16384: return block_fourier_instance<T, 13, BLOCK_BIG_PL>(bsk_std, fbsk, tables, polys, stream);
+    case 256: return block_fourier_instance<T, 7, 1>(bsk_std, fbsk, tables, polys, levels, stream);
+    case 512: return block_fourier_instance<T, 8, 2>(bsk_std, fbsk, tables, polys, levels, stream);
+    case 1024: return block_fourier_instance<T, 9, 3>(bsk_std, fbsk, tables, polys, levels, stream);
+    case 2048: return block_fourier_instance<T, 10, 3>(bsk_std, fbsk, tables, polys, levels, stream);
+    case 4096: return block_fourier_instance<T, 11, 3>(bsk_std, fbsk, tables, polys, levels, stream);
+    case 8192: return block_fourier_instance<T, 12, BLOCK_BIG_PL>(bsk_std, fbsk, tables, polys, levels, stream);
+    case 16384: return block_fourier_instance<T, 13, BLOCK_BIG_PL>(bsk_std, fbsk, tables, polys, levels, stream);
   }
   return fail(CAMD_EINVAL, "the register-blocked kernel has no instance for this polynomial size");
 }
@@ -698,8 +859,10 @@ int block_launch_pbs(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream) {
   return fail(CAMD_EINVAL, "the register-blocked kernel has no instance for this parameter set");
 }
 
-template int block_bsk_to_fourier<uint64_t>(const uint64_t*, double2*, const double2*, uint32_t, size_t, hipStream_t);
-template int block_bsk_to_fourier<uint32_t>(const uint32_t*, double2*, const double2*, uint32_t, size_t, hipStream_t);
+template int block_bsk_to_fourier<uint64_t>(const uint64_t*, double2*, const double2*, uint32_t, size_t, uint32_t,
+                                             hipStream_t);
+template int block_bsk_to_fourier<uint32_t>(const uint32_t*, double2*, const double2*, uint32_t, size_t, uint32_t,
+                                             hipStream_t);
 template int block_launch_pbs<uint64_t>(const PbsLaunch<uint64_t>&, unsigned, hipStream_t);
 template int block_launch_pbs<uint32_t>(const PbsLaunch<uint32_t>&, unsigned, hipStream_t);
 
