@@ -104,7 +104,9 @@ int camd_server_key_variant(const camd_server_key* key, int* variant);
  * from the pointer), which is how a key is written to and read back from a file: synchronise
  * `stream` before reading an exported host buffer. The layout of the Fourier part depends on
  * the kernel family, so the variant and params given to import must be those of the exporting
- * key (camd_server_key_variant, camd_server_key_params). */
+ * key (camd_server_key_variant, camd_server_key_params). It is also private to the library
+ * build (the order of the spectrum follows the kernels' thread layout): import only blobs that
+ * the same build of the library exported. */
 int camd_server_key_blob_size(const camd_server_key* key, size_t* bytes);
 int camd_server_key_export_blob(const camd_server_key* key, void* device_dst, void* stream);
 int camd_server_key_import_blob(camd_context* ctx, const camd_params* params, int pbs_variant,
