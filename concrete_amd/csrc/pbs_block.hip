@@ -123,6 +123,14 @@ __device__ __forceinline__ double2 stage_twiddle(bool from_global, const double2
 // The arguments lo, top, B and from_global of the helpers below are compile-time constants at
 // every call site (the pass loops are fully unrolled), so all index arithmetic folds.
 
+// In the pass whose in-register bits start at bit 0 the butterfly index is the register index
+// alone, and index 0 selects W^0 = (1, -0) of every stage: that product is left out. It returns its
+// operand up to the sign of a zero, which no later step can tell apart (sums, products and the
+// rounding to the torus treat both zeros alike), so the output words are unchanged.
+__device__ __forceinline__ constexpr bool unit_twiddle(uint32_t lo, int r, int s) {
+  return lo == 0 && (r & ((1 << s) - 1)) == 0;
+}
+
 // forward (decimation in frequency) stages lo+PL-1 ... lo, those above `top` already done
 template <int PL>
 __device__ __forceinline__ void forward_stages(double2 (&x)[1 << PL], uint32_t lo, uint32_t top, uint32_t B,
@@ -138,9 +146,13 @@ __device__ __forceinline__ void forward_stages(double2 (&x)[1 << PL], uint32_t l
     for (int r = 0; r < P; r++) {
       if (r & (1 << s)) continue;
       const uint32_t j = ((uint32_t)(r & ((1 << s) - 1)) << lo) | tl;
-      const double2 w = stage_twiddle(from_global, gtw, ltw, b, j, B);
       const double2 a = x[r], c = x[r | (1 << s)];
       x[r] = cadd(a, c);
+      if (unit_twiddle(lo, r, s)) {
+        x[r | (1 << s)] = csub(a, c);
+        continue;
+      }
+      const double2 w = stage_twiddle(from_global, gtw, ltw, b, j, B);
       x[r | (1 << s)] = cmul(csub(a, c), w);
     }
     __builtin_amdgcn_sched_barrier(0);  // keeps the twiddle loads of later stages from piling up in registers
@@ -162,9 +174,9 @@ __device__ __forceinline__ void inverse_stages(double2 (&x)[1 << PL], uint32_t l
     for (int r = 0; r < P; r++) {
       if (r & (1 << s)) continue;
       const uint32_t j = ((uint32_t)(r & ((1 << s) - 1)) << lo) | tl;
-      const double2 w = stage_twiddle(from_global, gtw, ltw, b, j, B);
       const double2 a = x[r];
-      const double2 c = cmul_conj(x[r | (1 << s)], w);
+      const double2 c = unit_twiddle(lo, r, s) ? x[r | (1 << s)]
+                                               : cmul_conj(x[r | (1 << s)], stage_twiddle(from_global, gtw, ltw, b, j, B));
       x[r] = cadd(a, c);
       x[r | (1 << s)] = csub(a, c);
     }
