@@ -10,7 +10,9 @@
 //   * Transforms: each thread keeps P points in registers and runs log2(P) radix-2 stages on
 //     them between exchanges; an exchange goes through one LDS image of the polynomial with
 //     16-byte accesses and an XOR swizzle chosen per exchange so that both the store and the
-//     load side are free of bank conflicts. Stage twiddles of the first pass (the top log2(P)
+//     load side are free of bank conflicts, or, where it only trades lane bits that have a cheap
+//     register transposition, through lane swaps and row shifts (see block_shuffles).
+//     Stage twiddles of the first pass (the top log2(P)
 //     stages, whose tables are the large ones) come from global memory, all others from a
 //     compact per-stage copy in LDS.
 //   * The Fourier-domain sums of the external product stay in registers ((k+1) x P complex per
@@ -27,8 +29,9 @@
 // radix-2 flow graph fixes, for every element, the sequence of IEEE-754 operations applied to
 // it; which thread executes a butterfly does not matter. Contraction is off, fused operations
 // are explicit fma(), twiddles are the host-computed tables of the fallback kernel, the
-// accumulation order over (level, row) and the rounding are the same. Output ciphertexts are
-// therefore bit-identical to the fallback kernel's and to the CPU restatement's.
+// accumulation order over (level, row) and the rounding are the same. The one product left out
+// is the one by W^0 = (1, -0) (see unit_twiddle), which can only change the sign of a zero. Output
+// ciphertexts are therefore bit-identical to the fallback kernel's and to the CPU restatement's.
 #pragma clang fp contract(off)
 #include "kernels.hpp"
 
