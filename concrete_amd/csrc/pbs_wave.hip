@@ -609,6 +609,7 @@ __device__ __forceinline__ void fft512_inverse_multi(double2 (&x)[S][8], int lan
 template <typename T, int K, int BL>
 __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   constexpr int N = 1024, M = 512, LOGN = 10, L = 1, R = K + 1;
+  constexpr int START_STAGGER = 34;   // s_sleep units (64 cycles) between the starts of a CU's waves
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
   stage_folded_tables(tab, a.tables, 256);
@@ -656,6 +657,16 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
     a_cur = wave_uniform(in[i]);  // in[n] is the body: readable
   }
 
+  // The four waves of a CU run the same program and share its LDS; they leave the rendezvous (and
+  // the start of the launch) together. Wave w starts its iterations w eighths of an iteration
+  // late (34 x 64 cycles each), so that the store-heavy exchanges of one wave fall beside the
+  // arithmetic of the others from the first iteration on instead of after the waves have drifted
+  // apart by themselves: 90.9 -> 90.1 ms per 2^14 (17, 68 and 100 x 64 cycles: 90.0-90.2). The
+  // delay has to sit here, behind the table rotation and the scan for the first mask element
+  // (ahead of them it gains nothing: their loads realign the waves), and ahead of the zeroing of
+  // the parked registers, so that the compiler has no reason to move one of those afterwards.
+  for (int k = 0; k < wave; k++) __builtin_amdgcn_s_sleep(START_STAGGER);
+
   // The GGSW of one iteration is R*R slabs of 8 registers (one 8 KiB slab per (row, col)).
   // NA of them are parked in the accumulation registers (AGPRs): their loads are issued one
   // iteration ahead and write the AGPRs directly, so they cost no vector registers while in
@@ -677,6 +688,7 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
   bool work = false;
   uint32_t a_hat = 0, cur = 0;
 #ifdef CAMD_PROFILE
+  const uint64_t c_begin = __builtin_amdgcn_s_memtime(), r_begin = __builtin_amdgcn_s_memrealtime();
   uint64_t tG = 0, tF = 0, tM = 0, tL = 0, tI = 0, tR = 0, t0, t1;
 #define STAMP(acc) t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1;
 #else
@@ -874,10 +886,12 @@ __global__ __launch_bounds__(256, 1) void wave_pbs_kernel_v2(PbsLaunch<T> a) {
     cur = next_i;
   }
 #ifdef CAMD_PROFILE
-  if ((ct == 0 || ct == 5000) && lane == 0)
-    printf("ct %lu cycles per iteration: gather %lu fwd %lu mac %lu load %lu inv %lu round %lu\n", (unsigned long)ct,
+  if ((ct == 0 || ct == 5000 || ct == 9001) && lane == 0) {
+    const uint64_t dc = __builtin_amdgcn_s_memtime() - c_begin, dr = __builtin_amdgcn_s_memrealtime() - r_begin;
+    printf("ct %lu cycles per iteration: gather %lu fwd %lu mac %lu load %lu inv %lu round %lu | total memtime %lu realtime(100MHz) %lu\n", (unsigned long)ct,
            (unsigned long)(tG / n), (unsigned long)(tF / n), (unsigned long)(tM / n), (unsigned long)(tL / n),
-           (unsigned long)(tI / n), (unsigned long)(tR / n));
+           (unsigned long)(tI / n), (unsigned long)(tR / n), (unsigned long)dc, (unsigned long)dr);
+  }
 #endif
 
   T* out = a.ct_out + ct * a.out_stride;
