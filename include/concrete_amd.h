@@ -161,8 +161,10 @@ int camd_reserve(camd_server_key* key, size_t count);
 int camd_server_key_check(camd_server_key* key, void* stream);
 int camd_ks_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids,
                              void* ct_out, size_t count, void* stream);
-/* camd_ks_pbs_batch_device for callers that cannot allocate (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference. It
+/* camd_ks_pbs_batch_device for callers that cannot allocate (tight serving loops, harnesses that
+ * forbid hipMalloc). It has no counterpart in the reference. It is not meant to be captured into a
+ * HIP graph: like every call on a key it reads the key's host status word and records the key's
+ * completion event on `stream`. It
  * calls no hipMalloc, hipFree or other allocating routine: the keyswitch output and the kernels'
  * counters live in a fixed 16 MiB + 4 KiB device array that is part of the library's code object
  * (each GPU holds its own copy for the life of the process). Limits: keys of the wave kernel

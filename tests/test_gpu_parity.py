@@ -142,6 +142,10 @@ def fft_variance(p, o):
     products per output polynomial, and decryption multiplies the mask errors by the binary secret
     key, so each CMUX - whatever its key bit - adds (k+1)L (1 + kN/2) var(e) to the phase."""
     n, k, N, L = p.lwe_dimension, p.glwe_dimension, p.polynomial_size, p.pbs_level
+    if o.bits == 32:
+        # 32-bit torus: the rounding of every CMUX's result to 2^-32 (variance 2^-64 / 12 per
+        # coefficient) is far above what the f64 transforms leave of products of 8-bit digits
+        return n * (1.0 + k * N / 2.0) * 2.0 ** -64 / 12.0
     half = 1 << (p.pbs_base_log - 1)
     rs = np.random.RandomState(5)
     M = N // 2
@@ -156,45 +160,112 @@ def fft_variance(p, o):
     return n * (k + 1) * L * (1.0 + k * N / 2.0) * np.concatenate(errs).var()
 
 
-def test_output_noise_variance_2_2(gpu_ctx, keys_2_2):
-    """Acceptance bar for the fast kernel: over 2^14 bootstraps the variance of the output phase
-    error stays within the predicted figure (gadget noise + the f64 transforms' rounding, the
-    tolerance the path is allowed) and does not exceed the oracle's (measured on a 4096-ciphertext
-    subset) beyond sampling error; decryptions agree ciphertext by ciphertext."""
-    ks = keys_2_2
-    p = ks.params
-    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
-    lut = ks.o.generate_accumulator(lambda x: x % 4)
-    dk.upload_lut(lut)
+def check_noise_variance(bits, count, sub, bound, gadget, got, want, key, nearest_of, label):
+    """The three assertions of the noise acceptance bar, shared by every wave instance:
+    gadget < variance < 1.2 x predicted for the GPU (all `count` outputs) and for the oracle (the
+    first `sub`), the two variances within (0.75, 1.15) of each other on the same inputs, and no
+    bias. `nearest_of(phase)` returns the plaintext the phase decodes to (same dtype), `key` the
+    secret key the outputs are under. Returns the decoded plaintexts of both."""
     from concrete_amd import client as CL
 
-    rng = CL.Rng(99)
-    count, sub = 1 << 14, 1 << 12
-    delta = O.shortint_delta(p)
-    msgs = np.arange(count) % 4
-    cts = CL.lwe_encrypt(rng, 64, ks.glwe, [int(m) * delta for m in msgs], ks.lwe_std)
-    got = dk.ks_pbs(cts)
-    want = ks.o.ks_pbs_batch(ks.ksk, ks.fbsk, lut, None, cts[:sub], threads=16)
+    word = np.uint64 if bits == 64 else np.uint32
+    signed = np.int64 if bits == 64 else np.int32
 
     def phase_error(out):
-        ph = CL.lwe_phase(64, ks.glwe, out).astype(np.uint64)
-        nearest = ((ph + np.uint64(delta // 2)) // np.uint64(delta)) * np.uint64(delta)   # wraps like the torus
-        return (ph - nearest).view(np.int64).astype(np.float64) / 2.0 ** 64, (nearest // np.uint64(delta)) % np.uint64(16)
+        ph = CL.lwe_phase(bits, key, out).astype(word)
+        nearest = nearest_of(ph)
+        return (ph - nearest).view(signed).astype(np.float64) / 2.0 ** bits, nearest
 
     err_g, dec_g = phase_error(got)
     err_w, dec_w = phase_error(want)
+    print(f"{label}: variance gpu {err_g.var():.4e} (subset {err_g[:sub].var():.4e}), oracle {err_w.var():.4e}, "
+          f"predicted {bound:.4e} (gadget {gadget:.4e})")
+    assert gadget < err_g.var() < 1.2 * bound, (label, err_g.var(), bound)
+    assert gadget < err_w.var() < 1.2 * bound, (label, err_w.var(), bound)
+    ratio = err_g[:sub].var() / err_w.var()
+    assert 0.75 < ratio < 1.15, (label, ratio)
+    assert abs(err_g.mean()) < 4 * np.sqrt(bound / count), (label, err_g.mean())   # no bias from the fast rounding
+    return dec_g, dec_w
+
+
+# every shortint set whose default kernel is a wave instance: N = 1024 (one schedule, four sets that
+# differ in the moduli only: 2_2 stands for them) and the three N = 512 sets, which differ in n and
+# in the keyswitch decomposition (concrete-shortint/src/parameters/mod.rs:215-304)
+WAVE_SHORTINT_SETS = ["PARAM_MESSAGE_2_CARRY_2", "PARAM_MESSAGE_1_CARRY_2", "PARAM_MESSAGE_2_CARRY_1", "PARAM_MESSAGE_3_CARRY_0"]
+
+
+@pytest.mark.parametrize("pname", WAVE_SHORTINT_SETS)
+def test_output_noise_variance(gpu_ctx, pname):
+    """Acceptance bar for the fast kernels, for every shortint set CAMD_PBS_AUTO sends to a wave
+    instance: the variance of the output phase error stays within the predicted figure (gadget
+    noise + the f64 transforms' rounding, the tolerance the path is allowed) and does not exceed
+    the oracle's (measured on a 4096-ciphertext subset of the same inputs) beyond sampling error;
+    decryptions agree ciphertext by ciphertext. 2^14 bootstraps at 2_2, 2^13 at the N = 512 sets."""
+    from concrete_amd import client as CL
+    from concrete_amd.backend import CAMD_PBS_AUTO
+
+    p = getattr(P, pname)
+    ks = get_keys(p, 64)
+    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_AUTO)
+    assert dk.variant == CAMD_PBS_WAVE
+    msg = p.message_modulus
+    lut = ks.o.generate_accumulator(lambda x: x % msg)
+    dk.upload_lut(lut)
+    rng = CL.Rng(99)
+    count, sub = (1 << 14 if p.polynomial_size == 1024 else 1 << 13), 1 << 12
+    space = p.message_modulus * p.carry_modulus
+    delta = O.shortint_delta(p)
+    msgs = np.arange(count) % msg
+    cts = CL.lwe_encrypt(rng, 64, ks.glwe, [int(m) * delta for m in msgs], ks.lwe_std)
+    got = dk.ks_pbs(cts)
+    want = ks.o.ks_pbs_batch(ks.ksk, ks.fbsk, lut, None, cts[:sub], threads=16)
+    gadget = gadget_variance(p)
+    bound = gadget + fft_variance(p, ks.o)
+    nearest = lambda ph: ((ph + np.uint64(delta // 2)) // np.uint64(delta)) * np.uint64(delta)   # wraps like the torus
+    near_g, near_w = check_noise_variance(64, count, sub, bound, gadget, got, want, ks.glwe, nearest, pname)
+    dec_g, dec_w = (near_g // np.uint64(delta)) % np.uint64(space), (near_w // np.uint64(delta)) % np.uint64(space)
     # identical decryption wherever the oracle was run; wrong boxes only at the parameter set's own rate
     assert np.array_equal(dec_g[:sub], dec_w)
     assert np.count_nonzero(dec_g != msgs.astype(np.uint64)) <= 8       # expectation 2^14 * 2^-13.9 = 1.1
-    gadget, fft = gadget_variance(p), fft_variance(p, ks.o)
-    bound = gadget + fft
-    print(f"variance: gpu {err_g.var():.4e} (subset {err_g[:sub].var():.4e}), oracle {err_w.var():.4e}, "
-          f"predicted {bound:.4e} = gadget {gadget:.4e} + f64 transforms {fft:.4e}")
-    assert gadget < err_g.var() < 1.2 * bound, (err_g.var(), bound)
-    assert gadget < err_w.var() < 1.2 * bound
-    ratio = err_g[:sub].var() / err_w.var()
-    assert 0.75 < ratio < 1.15, ratio       # radix-8 transforms round less often than the oracle's radix-2
-    assert abs(err_g.mean()) < 4 * np.sqrt(bound / count)               # no bias from the fast rounding
+    dk.close()
+
+
+@pytest.mark.parametrize("params,pname", [(P.DEFAULT_PARAMETERS, "DEFAULT_PARAMETERS"), (P.TFHE_LIB_PARAMETERS, "TFHE_LIB_PARAMETERS")])
+def test_output_noise_variance_boolean(gpu_ctx, params, pname):
+    """The same bar for the two boolean sets (concrete-boolean/src/parameters/mod.rs:83-111), whose
+    default kernels are wave instances too: 2^13 NAND inputs (the gate's linear combination of two
+    fresh encryptions, engine/mod.rs:388-397) are bootstrapped; the phase of each output under the
+    GLWE key is compared with +-2^29 (lib.rs:76-82). The oracle runs on the first 2^12."""
+    from concurrent.futures import ThreadPoolExecutor
+    from concrete_amd import client as CL
+    from concrete_amd.backend import CAMD_PBS_AUTO
+
+    p = params
+    ks = get_keys(p, 32)
+    o = ks.o
+    dk = make_device_key(gpu_ctx, ks, CAMD_PBS_AUTO)
+    assert dk.variant == CAMD_PBS_WAVE
+    acc = o.boolean_accumulator()
+    dk.upload_lut(acc)
+    rng = CL.Rng(77)
+    count, sub = 1 << 13, 1 << 12
+    T, F = 1 << 29, 7 << 29
+    a_bits, b_bits = (np.arange(count) & 1).astype(bool), ((np.arange(count) >> 1) & 1).astype(bool)
+    ca = CL.lwe_encrypt(rng, 32, ks.small, np.where(a_bits, T, F), p.lwe_modular_std_dev)
+    cb = CL.lwe_encrypt(rng, 32, ks.small, np.where(b_bits, T, F), p.lwe_modular_std_dev)
+    cts = (np.uint32(0) - (ca + cb)).astype(np.uint32)
+    cts[:, -1] += np.uint32(T)
+    got = dk.pbs(cts)
+    with ThreadPoolExecutor(16) as pool:       # the oracle call releases the interpreter lock
+        want = np.stack(list(pool.map(lambda c: o.bootstrap(ks.fbsk, acc, c), cts[:sub])))
+    gadget = gadget_variance(p)
+    bound = gadget + fft_variance(p, o)
+    nearest = lambda ph: np.where(ph < np.uint32(1 << 31), np.uint32(T), np.uint32(F)).astype(np.uint32)
+    near_g, near_w = check_noise_variance(32, count, sub, bound, gadget, got, want, ks.glwe, nearest, pname)
+    nand = ~(a_bits & b_bits)
+    assert np.array_equal(near_g[:sub], near_w)
+    assert np.array_equal(near_g == np.uint32(T), nand)      # failure probability 2^-25 / 2^-165 per gate
+    dk.close()
 
 
 def test_wave_persistent_rounds_and_tail(gpu_ctx, keys_2_2):

@@ -29,8 +29,9 @@ def test_no_alloc_entry_point_matches_the_allocating_one(gpu_ctx):
     base = np.stack([o.lwe_encrypt(ks.rng, ks.glwe, (i % 16) * delta, ks.lwe_std) for i in range(64)])
     stream = torch.cuda.current_stream().cuda_stream
     # first call: more ciphertexts than one round of persistent waves (the kernels' counters are
-    # in use); second call: a smaller batch right behind it
-    for count in (2500, 300):
+    # in use); second call: a smaller batch right behind it; third: a batch small enough for the
+    # schedule that gives a ciphertext k+1 waves (at most one ciphertext per CU)
+    for count in (2500, 300, 40):
         rs = np.random.RandomState(count)
         cts = base[rs.randint(0, 64, size=count)].copy()
         cts[:, :8] += rs.randint(0, 2 ** 40, size=(count, 8)).astype(np.uint64)   # distinct masks, same message
@@ -40,7 +41,11 @@ def test_no_alloc_entry_point_matches_the_allocating_one(gpu_ctx):
         want = torch.zeros_like(d_in)
         got = torch.zeros_like(d_in)
         dk.ks_pbs_device(d_in, d_ids, want, count, stream)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]           # hipMemGetInfo: the device's free bytes
         dk.ks_pbs_device_noalloc(d_in, d_ids, got, count, stream)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before, "the call changed the device's free memory"
         dk.check(stream)
         assert torch.equal(got, want), count
         # and the words are right, not merely equal: a sample against the oracle's decryption
