@@ -206,6 +206,12 @@ class Ranks:
         self.dist.all_reduce(t)
         return int(t.item())
 
+    def census(self) -> dict:
+        """What the process group itself saw, for the JSON line: the number of ranks that took part
+        in a collective (not the launcher's WORLD_SIZE), and the backend that carried it."""
+        return {"ranks_reporting": self.sum_over_ranks(1),
+                "backend": self.backend if self.dist is not None else None}
+
     def close(self) -> None:
         if self.dist is not None:
             self.dist.destroy_process_group()
@@ -253,6 +259,10 @@ def plumbing(args) -> None:
     from concrete_amd.distributed import broadcast_blob, shard_bounds
 
     rk = Ranks(args)
+    if os.environ.get("CAMD_BENCH_FAIL_RANK") == str(rk.rank):
+        # failure injection for the test of the parent's exit status: this rank dies before its
+        # first collective, as a rank with a broken GPU would
+        raise SystemExit(f"bench.py: rank {rk.rank} fails on request (CAMD_BENCH_FAIL_RANK)")
     count = args.batch
     blob_bytes = 1 << 20   # stand-in for the 94.5 MB key blob
     meta = torch.zeros(2, dtype=torch.int64)
@@ -265,7 +275,7 @@ def plumbing(args) -> None:
         rk.barrier_sync()
         tb = time.perf_counter()
         blob, meta = broadcast_blob(blob, meta, 0)
-        key_broadcast_ms = (time.perf_counter() - tb) * 1e3
+        key_broadcast_ms = rk.max_over_ranks((time.perf_counter() - tb) * 1e3)
     checksum = int(blob.to(torch.int64).sum().item())
     lo, hi = shard_bounds(count * rk.world, rk.world, rk.rank)
     rk.barrier_sync()
@@ -274,12 +284,13 @@ def plumbing(args) -> None:
     elapsed = rk.max_over_ranks(time.perf_counter() - t0)
     owned = rk.sum_over_ranks(hi - lo)
     agree = rk.sum_over_ranks(int(checksum == int(torch.arange(blob_bytes, dtype=torch.int64).to(torch.uint8).to(torch.int64).sum())))
+    census = rk.census()
     if rk.rank == 0:
         emit({
             "metric": "bootstraps/sec (node), MESSAGE_2_CARRY_2", "value": None, "unit": "bootstraps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "none",
-            "plumbing_only": True, "backend": rk.backend,
+            "plumbing_only": True, **census,
             "config": {"workload": "rank plumbing only (PARAM_MESSAGE_2_CARRY_2 shards), no kernels",
                        "batch_per_gpu": count, "global_batch": owned},
             "ranks_with_identical_key_blob": agree, "key_broadcast_ms": key_broadcast_ms,
@@ -334,12 +345,13 @@ def other_workload(args) -> None:
     rk.barrier_sync()
     elapsed = rk.max_over_ranks(time.perf_counter() - t0)
     tm = dk.timing_read()
+    census = rk.census()
     if rank == 0:
         fpp = flop_per_pbs(p)
         achieved = count * fpp / (tm["pbs_ms"] * 1e-3) / 1e12 if tm["pbs_ms"] > 0 else 0.0
         emit({
             "metric": f"bootstraps/sec (node), {pname}", "value": count * world * args.steps / elapsed,
-            "unit": "bootstraps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "bootstraps/s", "n_gpus": world, **census, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (random key material and ciphertexts)",
             "config": {"workload": f"{pname} {'keyswitch+PBS' if order == 'ks_pbs' else 'PBS+keyswitch (gate bootstrap)'}, "
@@ -467,7 +479,7 @@ def main() -> None:
         tb = time.perf_counter()
         dk = replicate_server_key(ctx, p, dk if rank == 0 else None)
         rk.sync()
-        key_broadcast_ms = (time.perf_counter() - tb) * 1e3
+        key_broadcast_ms = rk.max_over_ranks((time.perf_counter() - tb) * 1e3)   # the slowest rank's
     key_setup_s = time.perf_counter() - t_key
 
     lut = CL.shortint_accumulator(p, lambda x: x % p.message_modulus)
@@ -509,6 +521,7 @@ def main() -> None:
     bad = torch.nonzero(got != expect).flatten()
     wrong_here = int(bad.numel())
     wrong = rk.sum_over_ranks(wrong_here)
+    census = rk.census()
 
     if rank == 0:
         total = count * world * args.steps
@@ -525,6 +538,9 @@ def main() -> None:
             "value": value,
             "unit": "bootstraps/s",
             "n_gpus": world,
+            # ranks that answered a collective and the backend that carried it (null backend: one
+            # rank, no process group): n_gpus above is the launcher's WORLD_SIZE, this is the group's
+            **census,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

@@ -228,6 +228,17 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128 and line["config"]["batch_per_gpu"] == 64
     assert line["ranks_with_identical_key_blob"] == 2 and line["key_broadcast_ms"] is not None
     assert line["plumbing_only"] is True and line["value"] is None
+    # counted through the process group, not read from the launcher's environment
+    assert line["ranks_reporting"] == 2 and line["backend"] == "gloo"
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    """A rank other than 0 that dies takes the whole run down: the parent that started the ranks
+    exits non-zero and no JSON line is printed (rank 0 never gets through its first collective)."""
+    r = _bench("--gpus", "2", "--plumbing", "--batch", "64", env={"CAMD_BENCH_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout
+    assert "rank 1 fails on request" in r.stderr
 
 
 def test_bench_rejects_a_gpus_flag_that_disagrees_with_the_launcher():
