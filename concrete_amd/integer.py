@@ -16,6 +16,8 @@ aliases: there is one schedule, and it is the batched one.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Iterable, List
 
@@ -144,14 +146,22 @@ class ServerKey(CrtServerOps):
     """server_key/mod.rs:24-68: a shortint server key whose max_degree leaves room for one carry.
     The radix operations are below; the CRT ones come from ``CrtServerOps``."""
 
-    def __init__(self, key: _si.ServerKey):
+    def __init__(self, key: _si.ServerKey, reference_schedule: bool | None = None):
         p = key.parameters
         key.max_degree = (p.message_modulus - 1) * p.carry_modulus - 1
         self.key = key
+        # True: a propagation step bootstraps exactly what the reference's does (two bootstraps
+        # per block, every block, radix_parallel/mod.rs:44-56). False (default): the bootstraps
+        # that cannot change any decryption are not launched (see _propagate_many). The
+        # environment variable CAMD_REFERENCE_SCHEDULE=1 makes True the default.
+        if reference_schedule is None:
+            reference_schedule = os.environ.get("CAMD_REFERENCE_SCHEDULE", "0") not in ("", "0")
+        self.reference_schedule = bool(reference_schedule)
 
     @classmethod
-    def new(cls, cks: ClientKey, ctx: Context | None = None, variant: int = CAMD_PBS_AUTO) -> "ServerKey":
-        return cls(_si.ServerKey.new(cks.key, ctx=ctx, variant=variant))
+    def new(cls, cks: ClientKey, ctx: Context | None = None, variant: int = CAMD_PBS_AUTO,
+            reference_schedule: bool | None = None) -> "ServerKey":
+        return cls(_si.ServerKey.new(cks.key, ctx=ctx, variant=variant), reference_schedule=reference_schedule)
 
     @classmethod
     def from_shortint(cls, cks: ClientKey, key: _si.ServerKey) -> "ServerKey":
@@ -176,17 +186,20 @@ class ServerKey(CrtServerOps):
         # refreshes its noise; every degree check that follows treats it as it treats a fresh
         # block). Skipping it is what makes an operation on fresh inputs start without a
         # propagation chain of launches.
-        pairs = [(c, i) for c, i in pairs if c.blocks[i].degree >= self.key.message_modulus]
+        ref = self.reference_schedule
+        if not ref:
+            pairs = [(c, i) for c, i in pairs if c.blocks[i].degree >= self.key.message_modulus]
         carries = []
         with self.key.deferred():
             for ctxt, index in pairs:
                 # radix/mod.rs:58-68 extracts the carry of the last block too and then drops it;
-                # that bootstrap has no effect on any output, so it is not launched.
+                # that bootstrap has no effect on any output, so it is only launched under the
+                # reference's schedule.
                 last = index >= len(ctxt.blocks) - 1
-                carries.append(None if last else self.key.carry_extract(ctxt.blocks[index]))
+                carries.append(None if (last and not ref) else self.key.carry_extract(ctxt.blocks[index]))
                 self.key.message_extract_assign(ctxt.blocks[index])
         for (ctxt, index), carry in zip(pairs, carries):
-            if carry is not None:
+            if carry is not None and index < len(ctxt.blocks) - 1:
                 self.key.unchecked_add_assign(ctxt.blocks[index + 1], carry)
 
     def propagate(self, ctxt: RadixCiphertext, index: int) -> None:

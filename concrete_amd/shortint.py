@@ -291,6 +291,10 @@ class ServerKey(ShortintOps):
         done so the requests go to the GPU together. Operations take turns (one runs at a time),
         so the result is that of calling them one after the other. Returns their results in order.
         """
+        if self._queue is not None:
+            # the workers' bootstraps would join the caller's deferred queue instead of parking,
+            # and dependent steps inside a thunk would read ciphertexts that were never bootstrapped
+            raise RuntimeError("gather() inside deferred(): the operations of a deferred block must not depend on bootstrap results")
         return _Gather(self, list(thunks)).run()
 
     def keyswitch_programmable_bootstrap_assign(self, ct: Ciphertext, acc: LookupTable) -> None:
@@ -416,6 +420,8 @@ class _Gather:
         self.key._tls.gather = self
         self.key._tls.index = w
         try:
+            if self.failure is not None:   # the caller gave up before this operation started
+                raise self.failure
             self.results[w] = self.thunks[w]()
         except BaseException as e:  # re-raised by run() in the caller's thread
             self.errors[w] = e
@@ -426,6 +432,8 @@ class _Gather:
 
     def park(self, items) -> None:
         w = self.key._tls.index
+        if self.failure is not None:       # the caller has given up: do not wait for a launch that will not come
+            raise self.failure
         self.pending[w] = list(items)
         self.arrived.release()
         self.resume[w].acquire()
@@ -437,22 +445,31 @@ class _Gather:
         for t in threads:
             t.start()
         live = list(range(len(self.thunks)))
-        while live:
-            for w in live:                 # one at a time: each runs to its next launch point
+        try:
+            while live:
+                for w in live:                 # one at a time: each runs to its next launch point
+                    self.resume[w].release()
+                    self.arrived.acquire()
+                batch = []
+                for w in live:
+                    if self.pending[w]:
+                        batch.extend(self.pending[w])
+                    self.pending[w] = None
+                live = [w for w in live if not self.done[w]]
+                if batch:
+                    # inside an outer gather this parks in turn; otherwise it is the launch
+                    try:
+                        self.key._launch(batch)
+                    except BaseException as e:
+                        self.failure = e
+        except BaseException as e:
+            # the caller was interrupted while the workers are parked (KeyboardInterrupt in
+            # acquire): hand every parked operation the failure so that its thread unwinds
+            # instead of waiting forever, then let the interruption through
+            self.failure = self.failure or e
+            for w in range(len(self.thunks)):
                 self.resume[w].release()
-                self.arrived.acquire()
-            batch = []
-            for w in live:
-                if self.pending[w]:
-                    batch.extend(self.pending[w])
-                self.pending[w] = None
-            live = [w for w in live if not self.done[w]]
-            if batch:
-                # inside an outer gather this parks in turn; otherwise it is the launch
-                try:
-                    self.key._launch(batch)
-                except BaseException as e:
-                    self.failure = e
+            raise
         for t in threads:
             t.join()
         if self.failure is not None:

@@ -14,16 +14,41 @@ def gpu_keys(gpu_ctx):
     return OC.make_keys(n_override=None, backend="gpu", ctx=gpu_ctx)
 
 
+def attributed(sks, tally):
+    """Every wrong output the tally let through has to come from a bootstrap that also fails on the
+    CPU oracle for the same input (the parameter set's own failure rate), never from the GPU path."""
+    audit = sks.key
+    before = len(audit.failed)
+
+    def finish():
+        checked, failed, own = audit.attribute()
+        print(f"bootstraps audited so far: {checked}; failed {failed} (expected {checked * 2.0 ** -13.9:.1f} "
+              f"at the parameter set's rate); not shared with the CPU oracle: {own}")
+        assert own == 0, "a bootstrap failed on the GPU and not on the oracle"
+        assert tally.bad == 0 or len(audit.failed) > before, "wrong outputs without a failed bootstrap"
+
+    return finish
+
+
 @pytest.mark.parametrize("device", [False, True])
 def test_shortint_operation_layer(gpu_keys, device):
     cks, sks = gpu_keys
-    OC.check_shortint_ops(cks, sks, device=device, tally=OC.Tally(per_check=1, total=2))
+    tally = OC.Tally(per_check=1, total=2)
+    finish = attributed(sks, tally)
+    OC.check_shortint_ops(cks, sks, device=device, tally=tally)
+    finish()
 
 
+@pytest.mark.parametrize("reference_schedule", [False, True])
 @pytest.mark.parametrize("device", [False, True])
-def test_radix_fheuint8(gpu_keys, device):
+def test_radix_fheuint8(gpu_keys, device, reference_schedule):
+    """Once with the bootstraps that cannot change a decryption left out (the default), once with
+    exactly the reference's (radix_parallel/mod.rs:44-56: two per block in every propagation step)."""
     cks, sks = gpu_keys
-    OC.check_radix_ops(cks, sks, count=48, device=device, tally=OC.Tally(per_check=2, total=8))
+    tally = OC.Tally(per_check=2, total=8)
+    finish = attributed(sks, tally)
+    OC.check_radix_ops(cks, sks, count=48, device=device, tally=tally, reference_schedule=reference_schedule)
+    finish()
 
 
 @pytest.mark.parametrize("device", [False, True])
@@ -31,7 +56,10 @@ def test_gathered_operations(gpu_keys, device):
     """A multiplication, an addition with carries and a bitwise operation of different integers in
     one ``gather``: launches shared round by round, same decryptions."""
     cks, sks = gpu_keys
-    OC.check_gathered_operations(cks, sks, count=32, device=device, tally=OC.Tally(per_check=2, total=4))
+    tally = OC.Tally(per_check=2, total=4)
+    finish = attributed(sks, tally)
+    OC.check_gathered_operations(cks, sks, count=32, device=device, tally=tally)
+    finish()
 
 
 @pytest.mark.parametrize("device", [False, True])

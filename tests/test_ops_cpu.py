@@ -63,6 +63,36 @@ def test_i_crt_matches_direct_search():
             assert i_crt(basis, [v % m for m in basis]) == v
 
 
+def test_radix_layer_on_oracle_reference_schedule():
+    cks, sks = OC.make_keys()
+    OC.check_radix_ops(cks, sks, reference_schedule=True)
+
+
+def test_reference_schedule_issues_the_reference_bootstraps():
+    """smart_mul of two fresh 4-block integers under the reference's schedule: both operands fully
+    propagated (radix_parallel/mul.rs:319-322: 2 x 4 blocks x 2 bootstraps), the 16 block products
+    (mul.rs:157-181) and the propagations of the sum tree; the default schedule leaves out every
+    bootstrap of a block that has no carry and the carry of a last block."""
+    from concrete_amd import integer as INT
+
+    cks, sks = OC.make_keys()
+    icks = INT.RadixClientKey.__new__(INT.RadixClientKey)
+    icks.key, icks.num_blocks = cks, 4
+    counts = {}
+    for ref in (False, True):
+        isks = INT.ServerKey(sks, reference_schedule=ref)
+        a, b = icks.encrypt_many([13, 200, 255]), icks.encrypt_many([7, 99, 255])
+        before = sks.key.bootstraps
+        r = isks.smart_mul(a, b)
+        counts[ref] = (sks.key.bootstraps - before) // 3
+        assert np.array_equal(icks.decrypt(r), np.array([13 * 7, 200 * 99, 255 * 255]) % 256)
+    print("bootstraps per smart_mul of fresh FheUint8 operands:", counts)
+    # 48 = 16 (both operands) + 16 (block products) + 16 (the last level of the sum tree adds two
+    # integers of block degree 10, beyond max_degree 11: both are fully propagated; the first
+    # level's sums, 5 + 5, need none)
+    assert counts == {False: 22, True: 48}, counts
+
+
 def test_radix_multiplication_launch_count():
     """All 16 block products of a 4-block multiplication are one launch, whatever the batch."""
     from concrete_amd import integer as INT
