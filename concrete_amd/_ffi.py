@@ -48,6 +48,7 @@ SYMBOLS = {
     "camd_server_key_params": (_i, [_vp, _PP]),
     "camd_server_key_variant": (_i, [_vp, C.POINTER(_i)]),
     "camd_server_key_blob_size": (_i, [_vp, C.POINTER(_sz)]),
+    "camd_fourier_layout_id": (_i, [_PP, _i, C.POINTER(C.c_uint64)]),
     "camd_server_key_export_blob": (_i, [_vp, _vp, _vp]),
     "camd_server_key_import_blob": (_i, [_vp, _PP, _i, _vp, _sz, _vp, C.POINTER(_vp)]),
     "camd_lut_upload": (_i, [_vp, _vp, _u32p]),

@@ -62,6 +62,15 @@ class Context:
             pass
 
 
+def fourier_layout_id(params, variant: int, torus_bits: int | None = None) -> int:
+    """The library's id for the layout of the Fourier bootstrap key of ``params`` under kernel
+    family ``variant``; a stored blob is only valid while this value is the one it was stored with."""
+    cp = _ffi.make_params(params, torus_bits)
+    out = C.c_uint64()
+    check(_ffi.lib().camd_fourier_layout_id(C.byref(cp), int(variant), C.byref(out)))
+    return out.value
+
+
 class DeviceServerKey:
     """Fourier bootstrap key + keyswitch key + look-up tables resident on one GPU."""
 
@@ -111,6 +120,10 @@ class DeviceServerKey:
         v = C.c_int()
         check(_ffi.lib().camd_server_key_variant(self._h, C.byref(v)))
         return v.value
+
+    def layout_id(self) -> int:
+        """Identifies the order of the Fourier key inside this key's blob (see ``fourier_layout_id``)."""
+        return fourier_layout_id(self.params, self.variant, self.torus_bits)
 
     def blob_size(self) -> int:
         s = C.c_size_t()

@@ -813,6 +813,28 @@ int camd_server_key_export_blob(const camd_server_key* key, void* device_dst, vo
   return CAMD_OK;
 }
 
+int camd_fourier_layout_id(const camd_params* params, int pbs_variant, uint64_t* id) {
+  if (!params || !id) return fail(CAMD_EINVAL, "null argument");
+  int rc = validate_params(*params);
+  if (rc != CAMD_OK) return rc;
+  int variant = CAMD_PBS_GENERIC;
+  rc = pick_variant(*params, pbs_variant, &variant);
+  if (rc != CAMD_OK) return rc;
+  const uint64_t tag = variant == CAMD_PBS_WAVE ? wave_layout_tag(*params)
+                       : variant == CAMD_PBS_BLOCK ? block_layout_tag(*params) : generic_layout_tag(*params);
+  // FNV-1a over (family, shape of a key polynomial set, family tag)
+  const uint64_t words[] = {(uint64_t)variant, params->torus_bits, params->polynomial_size, params->glwe_dimension,
+                            params->pbs_level, tag};
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (uint64_t w : words)
+    for (int b = 0; b < 8; b++) {
+      h ^= (w >> (8 * b)) & 0xff;
+      h *= 0x100000001b3ull;
+    }
+  *id = h;
+  return CAMD_OK;
+}
+
 int camd_server_key_import_blob(camd_context* ctx, const camd_params* params, int pbs_variant, const void* device_src,
                                 size_t bytes, void* stream, camd_server_key** out) {
   if (!ctx || !params || !device_src || !out) return fail(CAMD_EINVAL, "null argument");

@@ -124,6 +124,15 @@ int generic_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* table
 template <typename T>
 int generic_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
 
+// ---- layout of the Fourier bootstrap key, per kernel family ----
+// Every compile-time choice that decides where a spectrum value lies in the key blob (points per
+// thread, lane renumbering, register/lane placement) plus a revision number that is raised with
+// any other change of the order. A blob is only valid for a library whose tag equals the one it
+// was exported under (camd_fourier_layout_id).
+uint64_t generic_layout_tag(const camd_params& p);
+uint64_t block_layout_tag(const camd_params& p);
+uint64_t wave_layout_tag(const camd_params& p);
+
 // ---- register-blocked workgroup-per-ciphertext bootstrap (pbs_block.hip) ----
 // uses the tables of the generic family; results are bit-identical to it
 bool block_supported(const camd_params& p);

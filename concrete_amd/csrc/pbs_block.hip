@@ -804,6 +804,17 @@ int block_fourier_instance(const T* bsk_std, double2* fbsk, const double2* table
 }  // namespace
 
 // instances: the (N, k) pairs of the reference's parameter sets
+// points per thread as a power of two, lane renumbering on or off, and the compile-time
+// configuration of the N >= 8192 instances all move spectrum values inside the key
+uint64_t block_layout_tag(const camd_params& p) {
+  uint32_t B = 0;
+  while ((2u << B) < p.polynomial_size) B++;
+  const uint64_t shuf = block_shuffles((int)(p.torus_bits / 8), (int)B, (int)p.pbs_level) ? 1 : 0;
+  constexpr uint64_t REVISION = 2;
+  return (REVISION << 32) | ((uint64_t)block_pl(p.polynomial_size) << 16) | (shuf << 8) | ((uint64_t)BLOCK_BIG_PL << 4) |
+         (uint64_t)BLOCK_BIG_CREG;
+}
+
 bool block_supported(const camd_params& p) {
   const uint32_t N = p.polynomial_size, k = p.glwe_dimension;
   const uint32_t L = p.pbs_level;

@@ -182,6 +182,12 @@ unsigned generic_threads(uint32_t N) {
 
 }  // namespace
 
+// bit-reversed frequency order of an in-place decimation-in-frequency transform, unscaled
+uint64_t generic_layout_tag(const camd_params& p) {
+  constexpr uint64_t REVISION = 1;
+  return (REVISION << 32) | p.polynomial_size;
+}
+
 size_t generic_tables_count(uint32_t N) { return (size_t)(N / 2) + (size_t)(N / 4 ? N / 4 : 1); }
 
 // cos and sin go through volatile pointers so that the compiler cannot merge the pair into one

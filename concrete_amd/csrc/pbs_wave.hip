@@ -1325,6 +1325,13 @@ static bool tfhe_lib_instance(const camd_params& p) {
   return p.torus_bits == 32 && p.polynomial_size == 1024 && p.glwe_dimension == 1 && p.pbs_level == 3 && p.pbs_base_log == 7;
 }
 
+// [register g][lane] with frequency 64 g + 8 (lane & 7) + (lane >> 3) at N = 1024 and the radix-4
+// digit order at N = 512, values pre-scaled by 1/(N/2): fixed by the transforms of these files
+uint64_t wave_layout_tag(const camd_params& p) {
+  constexpr uint64_t REVISION = 1;
+  return (REVISION << 32) | p.polynomial_size;
+}
+
 bool wave_supported(const camd_params& p) {
   if (p.polynomial_size == 1024 && p.torus_bits == 64)
     return p.glwe_dimension == 2 && p.pbs_level == 1 && p.pbs_base_log == 23;

@@ -36,7 +36,7 @@ from . import parameters as _params
 
 ENTITY_VERSION_V0 = 0
 FOURIER_MAGIC = b"CAMDFBSK"
-FOURIER_FORMAT = 1
+FOURIER_FORMAT = 2     # 2: the payload carries the library's layout id (camd_fourier_layout_id)
 
 
 class WireError(ValueError):
@@ -371,12 +371,13 @@ def deserialize_shortint_client_key(data, seed: int | None = None):
 
 def fourier_key_payload(device_key):
     """This library's payload for the Fourier bootstrap key: magic, format, kernel family, torus
-    bits, n, k, N, level, base log, byte count, bytes as they lie in device memory. Returns the
+    bits, layout id, n, k, N, level, base log, byte count, bytes as they lie in device memory. Returns the
     payload and the keyswitch-key bytes that follow the Fourier key in the device blob."""
     p = device_key.params
     blob = device_key.export_blob_host()
     fourier_bytes = (p.lwe_dimension * p.pbs_level * (p.glwe_dimension + 1) ** 2 * (p.polynomial_size // 2)) * 16
     w = Writer().raw(FOURIER_MAGIC).u32(FOURIER_FORMAT).u32(device_key.variant).u32(device_key.torus_bits)
+    w.u64(device_key.layout_id())
     w.u64(p.lwe_dimension).u64(p.glwe_dimension).u64(p.polynomial_size).u64(p.pbs_level).u64(p.pbs_base_log)
     w.byte_vec(blob[:fourier_bytes].tobytes())
     return w.finish(), blob[fourier_bytes:]
@@ -390,6 +391,19 @@ def parse_fourier_key_payload(data, p, torus_bits: int):
     fmt, variant, bits = r.u32(), r.u32(), r.u32()
     if fmt != FOURIER_FORMAT:
         raise WireError(f"unknown Fourier key format {fmt}")
+    # the bytes are in the order of the kernels that wrote them: a payload from a build whose
+    # kernels lay the spectrum out differently is refused (the key cache then regenerates)
+    from .backend import fourier_layout_id
+
+    layout = r.u64()
+    if variant not in (1, 2, 3):
+        raise WireError(f"unknown kernel family {variant}")
+    try:
+        ours = fourier_layout_id(p, variant, torus_bits)
+    except Exception as e:          # no instance of that family for this parameter set in this build
+        raise WireError(f"Fourier key of kernel family {variant}: {e}") from e
+    if layout != ours:
+        raise WireError(f"Fourier key was laid out by another build of the library (layout id {layout:#x}, this build {ours:#x})")
     shape = (r.u64(), r.u64(), r.u64(), r.u64(), r.u64())
     want = (p.lwe_dimension, p.glwe_dimension, p.polynomial_size, p.pbs_level, p.pbs_base_log)
     if shape != want or bits != torus_bits:

@@ -105,9 +105,16 @@ int camd_server_key_variant(const camd_server_key* key, int* variant);
  * `stream` before reading an exported host buffer. The layout of the Fourier part depends on
  * the kernel family, so the variant and params given to import must be those of the exporting
  * key (camd_server_key_variant, camd_server_key_params). It is also private to the library
- * build (the order of the spectrum follows the kernels' thread layout): import only blobs that
- * the same build of the library exported. */
+ * build (the order of the spectrum follows the kernels' thread layout): import only blobs whose
+ * layout id, taken with camd_fourier_layout_id when they were exported, equals the importing
+ * library's for the same params and variant (a raw blob carries no header; whoever stores one
+ * stores the id beside it and compares before importing). */
 int camd_server_key_blob_size(const camd_server_key* key, size_t* bytes);
+/* Identifies the order in which this build of the library lays out the Fourier bootstrap key of
+ * `params` under kernel family `pbs_variant` (AUTO resolves as in camd_server_key_create): a hash
+ * of the family, the shape and every compile-time choice that moves a spectrum value inside the
+ * blob. No counterpart in the reference, whose Fourier key layout is concrete-fft's own. */
+int camd_fourier_layout_id(const camd_params* params, int pbs_variant, uint64_t* id);
 int camd_server_key_export_blob(const camd_server_key* key, void* device_dst, void* stream);
 int camd_server_key_import_blob(camd_context* ctx, const camd_params* params, int pbs_variant,
                                 const void* device_src, size_t bytes, void* stream,

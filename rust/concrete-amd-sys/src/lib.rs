@@ -63,6 +63,7 @@ extern "C" {
     pub fn camd_server_key_params(key: *const CamdServerKey, out: *mut CamdParams) -> c_int;
     pub fn camd_server_key_variant(key: *const CamdServerKey, variant: *mut c_int) -> c_int;
     pub fn camd_server_key_blob_size(key: *const CamdServerKey, bytes: *mut usize) -> c_int;
+    pub fn camd_fourier_layout_id(params: *const CamdParams, pbs_variant: c_int, id: *mut u64) -> c_int;
     pub fn camd_server_key_export_blob(key: *const CamdServerKey, device_dst: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn camd_server_key_import_blob(ctx: *mut CamdContext, params: *const CamdParams, pbs_variant: c_int, device_src: *const c_void, bytes: usize, stream: *mut c_void, out: *mut *mut CamdServerKey) -> c_int;
     pub fn camd_lut_upload(key: *mut CamdServerKey, glwe_host: *const c_void, lut_id: *mut u32) -> c_int;

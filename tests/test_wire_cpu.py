@@ -143,6 +143,44 @@ def test_fourier_payload_of_another_writer_is_refused():
         wire.parse_fourier_key_payload(struct.pack("<I", 0) + b"\x00" * 64, p, 64)
 
 
+def test_fourier_payload_of_another_build_is_refused():
+    """The Fourier key bytes are in the order of the kernels that wrote them. The payload carries
+    the library's layout id for (parameter set, kernel family); one written under another id - a
+    build whose kernels place the spectrum differently - is refused as a WireError, which the key
+    cache treats as a miss. So is the format that had no id."""
+    import dataclasses
+
+    from concrete_amd.backend import fourier_layout_id
+
+    p = dataclasses.replace(P.PARAM_MESSAGE_2_CARRY_2, lwe_dimension=1)
+    size = p.lwe_dimension * p.pbs_level * (p.glwe_dimension + 1) ** 2 * (p.polynomial_size // 2) * 16
+
+    def payload(fmt, variant, layout):
+        w = wire.Writer().raw(wire.FOURIER_MAGIC).u32(fmt).u32(variant).u32(64)
+        if fmt >= 2:
+            w.u64(layout)
+        w.u64(p.lwe_dimension).u64(p.glwe_dimension).u64(p.polynomial_size).u64(p.pbs_level).u64(p.pbs_base_log)
+        w.byte_vec(bytes(size))
+        return w.finish()
+
+    ids = {v: fourier_layout_id(p, v, 64) for v in (1, 2, 3)}
+    assert len(set(ids.values())) == 3                      # the three families lay the key out differently
+    assert ids[2] == fourier_layout_id(p, 0, 64)            # AUTO resolves to the wave family for this set
+    other = dataclasses.replace(P.PARAM_MESSAGE_4_CARRY_4, lwe_dimension=1)
+    assert fourier_layout_id(other, 3, 64) != ids[3]
+    for v in (1, 2, 3):
+        variant, body = wire.parse_fourier_key_payload(payload(wire.FOURIER_FORMAT, v, ids[v]), p, 64)
+        assert variant == v and len(body) == size
+        with pytest.raises(wire.WireError, match="another build"):
+            wire.parse_fourier_key_payload(payload(wire.FOURIER_FORMAT, v, ids[v] ^ 1), p, 64)
+    with pytest.raises(wire.WireError, match="another build"):
+        wire.parse_fourier_key_payload(payload(wire.FOURIER_FORMAT, 2, ids[3]), p, 64)   # another family's order
+    with pytest.raises(wire.WireError, match="unknown Fourier key format"):
+        wire.parse_fourier_key_payload(payload(1, 2, 0), p, 64)
+    with pytest.raises(wire.WireError, match="unknown kernel family"):
+        wire.parse_fourier_key_payload(payload(wire.FOURIER_FORMAT, 9, ids[2]), p, 64)
+
+
 def test_param_names():
     assert keycache.param_name(P.PARAM_MESSAGE_2_CARRY_2) == "PARAM_MESSAGE_2_CARRY_2"
     assert keycache.FileStorage("some/dir").path(P.PARAM_MESSAGE_4_CARRY_4) == "some/dir/PARAM_MESSAGE_4_CARRY_4.bin"
