@@ -270,6 +270,7 @@ int key_fill(camd_server_key* key, const void* bsk_host, const void* ksk_host) {
 // the smallest batches of the N = 16384 sets, whose 98304 key rows the f64-FMA kernel spreads over
 // the chip slightly better (0.24 against 0.30 ms below 32 ciphertexts). CAMD_KS_MFMA_MIN overrides
 // the smallest batch that takes the matrix cores (0 = never).
+constexpr size_t KS_MFMA_MAX_COUNT = 65535u * 16u;   // launch_keyswitch_mfma's grid limit
 bool ks_use_mfma(const camd_server_key* key, size_t count) {
   if (!key->ks_limbs.ptr) return false;
   const char* e = std::getenv("CAMD_KS_MFMA_MIN");
@@ -277,6 +278,7 @@ bool ks_use_mfma(const camd_server_key* key, size_t count) {
     const long v = std::strtol(e, nullptr, 10);
     return v > 0 && count >= (size_t)v;
   }
+  if (count > KS_MFMA_MAX_COUNT) return false;   // beyond one launch of the matrix-core kernel: the f64-FMA form has no limit
   const size_t rows = key->big() * key->p.ks_level;
   return rows <= 32768 || count >= 32;
 }
@@ -320,8 +322,11 @@ int reserve_locked(camd_server_key* key, size_t count) {
   int rc = key->mid.ensure(count * mid_words * key->word);
   if (rc != CAMD_OK) return rc;
   if (ks_use_mfma(key, count)) {
-    rc = key->ks_digits.ensure(keyswitch_mfma_digit_bytes((uint32_t)key->big(), p.ks_level, count));
-    if (rc != CAMD_OK) return rc;
+    // Digit scratch of the matrix-core keyswitch (count x kN x level bytes). If the device cannot
+    // spare it the call still succeeds: run_ks sees the short buffer and takes the f64-FMA kernel,
+    // which needs no scratch.
+    if (key->ks_digits.ensure(keyswitch_mfma_digit_bytes((uint32_t)key->big(), p.ks_level, count)) != CAMD_OK)
+      (void)hipGetLastError();   // the failed allocation must not surface as the next launch's error
   }
   if (key->variant == CAMD_PBS_GENERIC) {
     unsigned grid = 1;

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(KSM_THREADS, 1) void ks_mfma_kernel(const int8_t* _
 
 bool keyswitch_mfma_supported(uint32_t in_dim, uint32_t base_log, uint32_t level) {
   const uint64_t K = (uint64_t)in_dim * level;
-  if (K % KSM_KT != 0 || base_log > 6) return false;
+  if (K % KSM_KT != 0 || base_log == 0 || base_log > 6) return false;
   // exact i32 accumulation: K * (B/2) * 128 < 2^31
   return K * (1ull << (base_log - 1)) * 128ull < (1ull << 31);
 }
