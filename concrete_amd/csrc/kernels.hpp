@@ -157,6 +157,10 @@ int wave512_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* table
 template <typename T>
 int wave512_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
 size_t wave_scratch_bytes();   // arrival counters of the persistent waves, cleared by every launch
+// the schedule with two waves per SIMD and a 32-bit accumulator (pbs_wave8.hip), reached through wave_launch_pbs
+bool wave8_supported(uint32_t torus_bits, uint32_t N, uint32_t k, uint32_t level, uint32_t base_log);
+template <typename T>
+int wave8_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
 void wave_fill_tables(uint32_t N, double2* host_tables);
 template <typename T>
 int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, const camd_params& p,

@@ -34,6 +34,7 @@
 // ciphertexts are therefore bit-identical to the fallback kernel's and to the CPU restatement's.
 #pragma clang fp contract(off)
 #include "kernels.hpp"
+#include "lane_swap.hpp"
 
 namespace camd {
 
@@ -236,39 +237,6 @@ constexpr bool block_acc_in_lds(int torus_bytes, int B) { return torus_bytes == 
 // number differs in that bit. Lane bits 5 and 4 have an instruction for exactly that
 // (v_permlane32_swap / v_permlane16_swap, one per register pair); bits 3 and 2 take two row shifts
 // whose bank mask writes only the lanes that receive. Bits 1 and 0 have no cheap form and stay in LDS.
-template <int CTRL, int BANK_MASK>
-__device__ __forceinline__ uint32_t dpp_into(uint32_t old, uint32_t src) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, BANK_MASK, false);
-}
-template <int PB>
-__device__ __forceinline__ void swap_words(uint32_t& a, uint32_t& b) {
-  static_assert(PB >= 2 && PB <= 5, "lane bit without a cheap transposition");
-  if constexpr (PB == 5) {
-    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    a = r[0]; b = r[1];
-  } else if constexpr (PB == 4) {
-    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-    a = r[0]; b = r[1];
-  } else if constexpr (PB == 3) {   // row_shr:8 into lanes 8..15, row_shl:8 into lanes 0..7
-    const uint32_t na = dpp_into<0x118, 0xC>(a, b);
-    b = dpp_into<0x108, 0x3>(b, a);
-    a = na;
-  } else {                          // row_shr:4 into banks 1 and 3, row_shl:4 into banks 0 and 2
-    const uint32_t na = dpp_into<0x114, 0xA>(a, b);
-    b = dpp_into<0x104, 0x5>(b, a);
-    a = na;
-  }
-}
-template <int PB>
-__device__ __forceinline__ void swap_complex(double2& a, double2& b) {
-  uint32_t a0 = (uint32_t)__double2loint(a.x), a1 = (uint32_t)__double2hiint(a.x);
-  uint32_t a2 = (uint32_t)__double2loint(a.y), a3 = (uint32_t)__double2hiint(a.y);
-  uint32_t b0 = (uint32_t)__double2loint(b.x), b1 = (uint32_t)__double2hiint(b.x);
-  uint32_t b2 = (uint32_t)__double2loint(b.y), b3 = (uint32_t)__double2hiint(b.y);
-  swap_words<PB>(a0, b0); swap_words<PB>(a1, b1); swap_words<PB>(a2, b2); swap_words<PB>(a3, b3);
-  a = make_double2(__hiloint2double((int)a1, (int)a0), __hiloint2double((int)a3, (int)a2));
-  b = make_double2(__hiloint2double((int)b1, (int)b0), __hiloint2double((int)b3, (int)b2));
-}
 // value (register bit S = rho, lane bit PB = lambda) moves to (register bit S = lambda, lane bit PB = rho)
 template <int PL, int S, int PB>
 __device__ __forceinline__ void transpose_bit(double2 (&x)[1 << PL]) {
