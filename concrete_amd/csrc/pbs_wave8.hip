@@ -43,7 +43,7 @@ constexpr size_t w8_slab_bytes() {
 }
 template <int K>
 constexpr size_t w8_lds_bytes() {
-  return TWS_COUNT * sizeof(double2) + W8_WAVES * w8_slab_bytes<K>();
+  return TWS_COUNT * sizeof(double2) + W8_WAVES * w8_slab_bytes<K>() + W8_WAVES * sizeof(uint32_t);   // + progress words
 }
 
 // The exchange of a transform that trades the register index with lane bits 5:3, in registers:
@@ -159,6 +159,9 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
   uint32_t* ct0 = (uint32_t*)slab;                                   // [R][N] high dwords of the accumulator
   double* pl = (double*)(slab + (size_t)R * N * sizeof(uint32_t));   // the exchange plane
   int lane = lane0;
+  // Progress of each wave (iterations done in its current round), for the priority rule below.
+  // Waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the four SIMDs in turn).
+  volatile uint32_t* progress = (volatile uint32_t*)(smem + TWS_COUNT * sizeof(double2) + W8_WAVES * w8_slab_bytes<K>());
 
   // the Fourier key through a buffer descriptor (at most 4 GiB: the N = 1024 sets take 57 MB)
   const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
       }
     }
 
+    if (lane == 0) progress[wave] = 0;
     // iterations whose mask element is zero are skipped, as the reference skips them
     uint32_t i = 0;
     T a_cur = wave_uniform(in[0]);
@@ -190,18 +194,38 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
       a_cur = wave_uniform(in[i]);   // in[n] is the body: readable
     }
 
+#ifdef CAMD_PROFILE
+    const uint64_t c_begin = __builtin_amdgcn_s_memtime(), r_begin = __builtin_amdgcn_s_memrealtime();
+    uint64_t tG = 0, tF = 0, tM = 0, tI = 0, tR = 0, t0, t1;
+#define STAMP(acc) t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1;
+#else
+#define STAMP(acc)
+#endif
     while (i < n) {
+#ifdef CAMD_PROFILE
+      t0 = __builtin_amdgcn_s_memtime();
+#endif
       // The lane number is made opaque once per CMUX: every address that depends on it (some
       // forty LDS and key offsets) is then recomputed here, a few integer instructions each,
       // instead of being hoisted out of the loop into registers the loop does not have.
       lane = lane0;
       asm volatile("" : "+v"(lane));
+      // The SIMD's arbiter favours the older of its two waves on every contended issue slot, so
+      // left alone one ciphertext of each pair finishes a third earlier than the other and the
+      // SIMD then runs a lone wave until the round ends. Each wave publishes its iteration count
+      // and takes the higher priority while it is behind its partner: the pair stays in step.
+      {
+        if (lane == 0) progress[wave] = i;
+        const uint32_t other = __builtin_amdgcn_readfirstlane(progress[wave ^ 4]);
+        if (other > i)
+          __builtin_amdgcn_s_setprio(2);
+        else
+          __builtin_amdgcn_s_setprio(0);
+      }
       const uint32_t a_hat = modswitch<T>(a_cur, LOGN) & (2 * N - 1);
       // this iteration's GGSW, [row][col][register g][lane]: byte offset of its first half-slab group
       const uint32_t key_off = i * (uint32_t)(NS * M * sizeof(double2));
-      // the next mask element is requested now and looked at after the CMUX
       i++;
-      const T a_nxt = in[i];
 
       // gather rotated - own (high dwords), one signed digit each
       double2 x[R][8];
@@ -239,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
         }
       }
 
+      STAMP(tG)
       // key values of frequency group g: NS loads of 16 bytes per lane (1 KiB per wave each)
       double2 kq[3][NS];
       // (buffer loads: one descriptor for the whole key in scalar registers, the slab in the
@@ -248,18 +273,18 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
         for (int sl = 0; sl < NS; sl++) {
           const auto w = __builtin_amdgcn_raw_buffer_load_b128(
-              key_rsrc, (int)((uint32_t)lane * 16u + (uint32_t)sl * (uint32_t)(M * sizeof(double2)) + (g & 3) * 1024),
-              (int)(key_off + (g >> 2) * 4096), 0);
+              key_rsrc, (int)((uint32_t)lane * 16u + (g & 3) * 1024),
+              (int)(key_off + (uint32_t)sl * (uint32_t)(M * sizeof(double2)) + (g >> 2) * 4096), 0);
           kq[g % 3][sl] = as_double2(__builtin_bit_cast(v4u, w));
         }
       };
       // groups 0 and 1 are requested ahead of the last forward pass, whose butterflies cover them
-      fft512_forward_multi1<R>(x, lane, tab, pl);
+      fft512_forward_multi1<R>(x, lane, tab, pl, [&](int) { load_group(0); });
       __builtin_amdgcn_sched_barrier(0);
-      load_group(0);
       load_group(1);
       __builtin_amdgcn_sched_barrier(0);
 
+      STAMP(tF)
       // x[c][g] <- sum_r GGSW[r][c][g] * x[r][g]: the sums of a group replace its spectra
 #pragma unroll
       for (int g = 0; g < 8; g++) {
@@ -277,8 +302,15 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
         __builtin_amdgcn_sched_barrier(0);
       }
 
+      STAMP(tM)
+      // the next mask element is requested here, where registers are free again, and looked at
+      // after the rounding (requested at the top of the CMUX it would have to be waited for and
+      // spilled at once: it would be live across the multiply-accumulate)
+      const T a_nxt = in[i];
+      __builtin_amdgcn_sched_barrier(0);
       fft512_inverse_multi1<R>(x, lane, tab, pl);
 
+      STAMP(tI)
       // untwist, round to 2^-32 of the torus, add into the accumulator
       {
         uint32_t old0[2][8], old1[2][8];
@@ -307,6 +339,7 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
         }
       }
 
+      STAMP(tR)
       // next active iteration
       a_cur = wave_uniform(a_nxt);
       while (i < n && a_cur == 0) {
@@ -315,6 +348,16 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
       }
     }
 
+    __builtin_amdgcn_s_setprio(0);
+    if (lane == 0) progress[wave] = n;   // done with this ciphertext: the partner keeps the higher priority until it is, too
+#ifdef CAMD_PROFILE
+    if ((ct == 0 || ct == 4 || ct == 5001 || ct == 5005 || ct == 9003) && lane == 0) {
+      const uint64_t dc = __builtin_amdgcn_s_memtime() - c_begin, dr = __builtin_amdgcn_s_memrealtime() - r_begin;
+      printf("ct %lu cycles per iteration: gather %lu fwd %lu mac %lu inv %lu round %lu | total memtime %lu realtime(100MHz) %lu\n",
+             (unsigned long)ct, (unsigned long)(tG / n), (unsigned long)(tF / n), (unsigned long)(tM / n), (unsigned long)(tI / n),
+             (unsigned long)(tR / n), (unsigned long)dc, (unsigned long)dr);
+    }
+#endif
     // sample extraction of coefficient 0; the low dwords are zero
     T* out = a.ct_out + ct * a.out_stride;
     for (int idx = lane; idx < K * N; idx += 64) {
