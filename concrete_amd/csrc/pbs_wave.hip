@@ -879,8 +879,10 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
   static_assert(lds <= 160 * 1024, "LDS budget exceeded");
   const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
   static const int schedule = []() {
+    // 3 (default where it has an instance): two waves per SIMD, pbs_wave8.hip; 2: one wave per
+    // SIMD with the key rows parked in registers; 1: the first schedule
     const char* e = getenv("CAMD_WAVE_SCHEDULE");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 3;
   }();
   // fewer ciphertexts than CUs: k+1 waves share each one
   {
@@ -902,7 +904,7 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     if (schedule == 3 && wave8_supported(64, 1024, K, L, BL)) return wave8_launch_pbs<T>(a, stream);
   }
   if constexpr (L == 1) {
-    if (schedule == 2) {
+    if (schedule == 2 || schedule == 3) {
       auto kern2 = wave_pbs_kernel_v2<T, K, BL>;
       CAMD_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int dev = 0, cus = 0;
@@ -919,7 +921,7 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
     }
   }
   if constexpr (L > 1) {
-    if (schedule == 2) {
+    if (schedule == 2 || schedule == 3) {
       auto kernr = wave_pbs_kernel_rows<T, K, L, BL>;
       CAMD_HIP(hipFuncSetAttribute((const void*)kernr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int dev = 0, cus = 0;

@@ -52,6 +52,9 @@ constexpr size_t w8_lds_bytes() {
 // vector instructions (32-bit moves, half the pipe time of an f64 instruction, issued beside the
 // other wave of the SIMD) instead of 16 LDS stores and 16 LDS loads on a pipe the whole CU shares.
 __device__ __forceinline__ void transpose_lane_bits_5_3(double2 (&x)[8]) {
+#ifdef W8_TIMING_NO_SHUFFLES   // timing-only build: wrong results
+  return;
+#endif
 #pragma unroll
   for (int r = 0; r < 8; r++)
     if (!(r & 4)) swap_complex<5>(x[r], x[r | 4]);
@@ -86,6 +89,9 @@ __device__ __forceinline__ void fft512_forward_multi1(double2 (&x)[S][8], int la
     const Tw8 k = load_tw8<false>(tab + TWS_B + lo, 8);
 #pragma unroll
     for (int s = 0; s < S; s++) {
+#ifdef W8_TIMING_NO_LDS_EXCHANGE   // timing-only build: wrong results
+      continue;
+#endif
       double re[8];
 #pragma unroll
       for (int b = 0; b < 8; b++) pl[hi * ROW + b * 8 + (lo ^ b)] = x[s][b].x;
@@ -111,6 +117,9 @@ __device__ __forceinline__ void fft512_inverse_multi1(double2 (&x)[S][8], int la
     const Tw8 k = load_tw8<false>(tab + TWS_B + lo, 8);
 #pragma unroll
     for (int s = 0; s < S; s++) {
+#ifdef W8_TIMING_NO_LDS_EXCHANGE   // timing-only build: wrong results
+      continue;
+#endif
       double re[8];
 #pragma unroll
       for (int q = 0; q < 8; q++) pl[hi * ROW + lo * 8 + (q ^ lo)] = x[s][q].x;
@@ -161,7 +170,11 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
   int lane = lane0;
   // Progress of each wave (iterations done in its current round), for the priority rule below.
   // Waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the four SIMDs in turn).
+#ifdef W8_PROGRESS_FLAT
   volatile uint32_t* progress = (volatile uint32_t*)(smem + TWS_COUNT * sizeof(double2) + W8_WAVES * w8_slab_bytes<K>());
+#else
+  uint32_t* progress = (uint32_t*)(smem + TWS_COUNT * sizeof(double2) + W8_WAVES * w8_slab_bytes<K>());
+#endif
 
   // the Fourier key through a buffer descriptor (at most 4 GiB: the N = 1024 sets take 57 MB)
   const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -215,8 +228,12 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
       // SIMD then runs a lone wave until the round ends. Each wave publishes its iteration count
       // and takes the higher priority while it is behind its partner: the pair stays in step.
       {
+        // plain LDS accesses between compiler fences (a volatile pointer would lose its address
+        // space and turn them into flat accesses that drain every counter)
+        asm volatile("" ::: "memory");
         if (lane == 0) progress[wave] = i;
         const uint32_t other = __builtin_amdgcn_readfirstlane(progress[wave ^ 4]);
+        asm volatile("" ::: "memory");
         if (other > i)
           __builtin_amdgcn_s_setprio(2);
         else
@@ -230,16 +247,20 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
       // gather rotated - own (high dwords), one signed digit each
       double2 x[R][8];
       {
-        uint32_t own0[2][4], own1[2][4], rot0[2][4], rot1[2][4];
+#ifndef W8_GATHER_AHEAD
+#define W8_GATHER_AHEAD 1
+#endif
+        constexpr int GA = W8_GATHER_AHEAD;   // units of half a polynomial requested ahead of the arithmetic
+        uint32_t own0[GA + 1][4], own1[GA + 1][4], rot0[GA + 1][4], rot1[GA + 1][4];
         auto issue = [&](int u) {
           const uint32_t* p = ct0 + (u >> 1) * N;
 #pragma unroll
           for (int t = 0; t < 4; t++) {
             const uint32_t j0 = 64 * (4 * (u & 1) + t) + lane, j1 = j0 + M;
-            own0[u & 1][t] = p[j0];
-            own1[u & 1][t] = p[j1];
-            rot0[u & 1][t] = p[(j0 - a_hat) & (N - 1)];
-            rot1[u & 1][t] = p[(j1 - a_hat) & (N - 1)];
+            own0[u % (GA + 1)][t] = p[j0];
+            own1[u % (GA + 1)][t] = p[j1];
+            rot0[u % (GA + 1)][t] = p[(j0 - a_hat) & (N - 1)];
+            rot1[u % (GA + 1)][t] = p[(j1 - a_hat) & (N - 1)];
           }
         };
         auto consume = [&](int u) {
@@ -247,16 +268,17 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
           for (int t = 0; t < 4; t++) {
             const int q = 4 * (u & 1) + t;
             const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
-            const int32_t g0 = digit_of_rotated_difference32<BL, LOGN>(rot0[u & 1][t], own0[u & 1][t], j0 - a_hat);
-            const int32_t g1 = digit_of_rotated_difference32<BL, LOGN>(rot1[u & 1][t], own1[u & 1][t], j1 - a_hat);
+            const int32_t g0 = digit_of_rotated_difference32<BL, LOGN>(rot0[u % (GA + 1)][t], own0[u % (GA + 1)][t], j0 - a_hat);
+            const int32_t g1 = digit_of_rotated_difference32<BL, LOGN>(rot1[u % (GA + 1)][t], own1[u % (GA + 1)][t], j1 - a_hat);
             x[u >> 1][q] = make_double2((double)g0, (double)g1);   // the twist is in the transform
           }
         };
-        issue(0);
+#pragma unroll
+        for (int u = 0; u < GA; u++) issue(u);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 2 * R; u++) {
-          if (u + 1 < 2 * R) issue(u + 1);
+          if (u + GA < 2 * R) issue(u + GA);
           __builtin_amdgcn_sched_barrier(0);
           consume(u);
           __builtin_amdgcn_sched_barrier(0);
@@ -313,27 +335,32 @@ __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
       STAMP(tI)
       // untwist, round to 2^-32 of the torus, add into the accumulator
       {
-        uint32_t old0[2][8], old1[2][8];
+#ifndef W8_ROUND_AHEAD
+#define W8_ROUND_AHEAD 1
+#endif
+        constexpr int RA = W8_ROUND_AHEAD;   // columns whose old values are requested ahead
+        uint32_t old0[RA + 1][8], old1[RA + 1][8];
         auto issue_old = [&](int c) {
           const uint32_t* pc = ct0 + c * N;
 #pragma unroll
           for (int q = 0; q < 8; q++) {
-            old0[c & 1][q] = pc[64 * q + lane];
-            old1[c & 1][q] = pc[64 * q + lane + M];
+            old0[c % (RA + 1)][q] = pc[64 * q + lane];
+            old1[c % (RA + 1)][q] = pc[64 * q + lane + M];
           }
         };
-        issue_old(0);
+#pragma unroll
+        for (int c = 0; c < RA && c < R; c++) issue_old(c);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < R; c++) {
-          if (c + 1 < R) issue_old(c + 1);
+          if (c + RA < R) issue_old(c + RA);
           __builtin_amdgcn_sched_barrier(0);
           uint32_t* pc = ct0 + c * N;
 #pragma unroll
           for (int q = 0; q < 8; q++) {
             const double2 v = untwist8(x[c][q], q);
-            pc[64 * q + lane] = torus_accumulate(old0[c & 1][q], v.x);
-            pc[64 * q + lane + M] = torus_accumulate(old1[c & 1][q], v.y);
+            pc[64 * q + lane] = torus_accumulate(old0[c % (RA + 1)][q], v.x);
+            pc[64 * q + lane + M] = torus_accumulate(old1[c % (RA + 1)][q], v.y);
           }
           __builtin_amdgcn_sched_barrier(0);
         }

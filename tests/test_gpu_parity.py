@@ -407,7 +407,7 @@ def test_other_wave_schedules_in_their_own_process():
     if os.environ.get("CAMD_WAVE_SCHEDULE") or os.environ.get("CAMD_WAVE_LATENCY"):
         pytest.skip("already running under a non-default schedule")
     here = os.path.abspath(__file__)
-    for schedule in ("1", "2"):
+    for schedule in ("1", "2"):      # the default is 3 (two waves per SIMD) where it has an instance
         env = dict(os.environ, CAMD_WAVE_SCHEDULE=schedule, CAMD_WAVE_LATENCY="0")
         res = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
                               "ks_pbs_parity_2_2 or trivial_bootstrap or persistent_rounds", "-p", "no:cacheprovider"],
