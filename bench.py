@@ -45,7 +45,7 @@ from concrete_amd.shortint import ClientKey  # noqa: E402
 FP64_PEAK_TFLOPS = 78.6
 SEED = 0xC0FFEE
 CPU_SAMPLE = 4096                # ciphertexts timed on the host cores (about 10 s on 16 threads)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2", "pmc_per_dispatch_final.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r3", "pmc_per_dispatch_final.json")
 CSRC = os.path.join(ROOT, "concrete_amd", "csrc")
 
 
@@ -549,7 +549,10 @@ def main() -> None:
         fpp = flop_per_pbs(p)
         pbs_s = tm["pbs_ms"] * 1e-3
         achieved = count * fpp / pbs_s / 1e12 if pbs_s > 0 else 0.0
-        traffic, provenance = (measured_traffic("wave_pbs_kernel") if dk.variant == 2 and count == 1 << 14
+        # the counters of the default schedule (two waves per SIMD); another schedule asked for through
+        # CAMD_WAVE_SCHEDULE has no committed summary
+        default_schedule = os.environ.get("CAMD_WAVE_SCHEDULE", "3") == "3"
+        traffic, provenance = (measured_traffic("wave8_pbs_kernel") if dk.variant == 2 and count == 1 << 14 and default_schedule
                                else (None, {"from_profile": None}))
         measured_peak = ctx.measure_fp64_fma_rate()   # 5 ms probe: what v_fma_f64 sustains on this GPU right now
         ks_macs = p.glwe_dimension * p.polynomial_size * p.ks_level * (p.lwe_dimension + 1)
