@@ -336,7 +336,7 @@ int reserve_locked(camd_server_key* key, size_t count) {
     unsigned grid = 1;
     rc = key->pbs_scratch.ensure(block_scratch_bytes(p, &grid, count));
   } else if (key->variant == CAMD_PBS_WAVE) {
-    rc = key->pbs_scratch.ensure(wave_scratch_bytes());
+    rc = key->pbs_scratch.ensure(wave_scratch_bytes(p, count));
   }
   return rc;
 }
@@ -942,9 +942,9 @@ int camd_ks_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint
 int camd_ks_pbs_batch_device_noalloc(camd_server_key* key, const void* ct_in, const uint32_t* lut_ids, void* ct_out,
                                      size_t count, void* stream) {
   if (!key || (!ct_in && count) || (!ct_out && count)) return fail(CAMD_EINVAL, "null argument");
-  if (key->variant != CAMD_PBS_WAVE)
-    return fail(CAMD_EINVAL, "the no-allocation entry point serves keys of the wave kernel family only (the other "
-                             "families need per-ciphertext scratch that grows with the batch)");
+  if (key->variant != CAMD_PBS_WAVE || !wave_scratch_is_fixed(key->p))
+    return fail(CAMD_EINVAL, "the no-allocation entry point serves keys of the wave kernel family with N <= 1024 only (the "
+                             "other kernels need per-ciphertext scratch that grows with the batch)");
   const size_t small1 = (size_t)key->p.lwe_dimension + 1, big1 = key->big() + 1;
   const size_t max_count = NOALLOC_MID_BYTES / (small1 * key->word);
   if (count > max_count)

@@ -156,7 +156,19 @@ template <typename T>
 int wave512_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream);
 template <typename T>
 int wave512_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
-size_t wave_scratch_bytes();   // arrival counters of the persistent waves, cleared by every launch
+// scratch of a launch of `count` ciphertexts: the arrival counters of the persistent waves (cleared by
+// every launch) or, for the N = 16384 instances, one accumulator slab per resident workgroup
+size_t wave_scratch_bytes(const camd_params& p, size_t count);
+bool wave_scratch_is_fixed(const camd_params& p);   // the scratch does not grow with the batch
+// the N = 16384 instances (pbs_wave16k.hip), reached through the wave_* functions
+bool wave16k_supported(const camd_params& p);
+size_t wave16k_tables_count();
+void wave16k_fill_tables(double2* t);
+size_t wave16k_scratch_bytes(unsigned* grid_out, size_t count, int cus);
+template <typename T>
+int wave16k_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream);
+template <typename T>
+int wave16k_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
 // the schedule with two waves per SIMD and a 32-bit accumulator (pbs_wave8.hip), reached through wave_launch_pbs
 bool wave8_supported(uint32_t torus_bits, uint32_t N, uint32_t k, uint32_t level, uint32_t base_log);
 template <typename T>

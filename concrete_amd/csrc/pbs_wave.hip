@@ -913,7 +913,7 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
       const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // LDS allows one workgroup per CU
       if (persistent < grid) {
         if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
-        CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
+        CAMD_HIP(hipMemsetAsync(a.scratch, 0, RENDEZVOUS_BYTES, stream));
       }
       hipLaunchKernelGGL(kern2, dim3(persistent), dim3(256), lds, stream, a);
       CAMD_HIP(hipGetLastError());
@@ -930,7 +930,7 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
       const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;
       if (persistent < grid) {
         if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
-        CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
+        CAMD_HIP(hipMemsetAsync(a.scratch, 0, RENDEZVOUS_BYTES, stream));
       }
       hipLaunchKernelGGL(kernr, dim3(persistent), dim3(256), lds, stream, a);
       CAMD_HIP(hipGetLastError());
@@ -946,7 +946,16 @@ int launch_instance(const PbsLaunch<T>& a, hipStream_t stream) {
 
 }  // namespace
 
-size_t wave_scratch_bytes() { return 2 * (size_t)SYNC_GROUPS * SYNC_STRIDE * sizeof(uint32_t); }
+bool wave_scratch_is_fixed(const camd_params& p) { return !wave16k_supported(p); }
+size_t wave_scratch_bytes(const camd_params& p, size_t count) {
+  if (wave16k_supported(p)) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+    return wave16k_scratch_bytes(nullptr, count, cus);
+  }
+  return RENDEZVOUS_BYTES;
+}
 
 // the boolean TFHE-lib parameters (32-bit torus, N = 1024, k = 1, three levels of base 2^7): first
 // schedule for large batches, the k+1-wave variant for small ones
@@ -964,17 +973,30 @@ uint64_t wave_layout_tag(const camd_params& p) {
 bool wave_supported(const camd_params& p) {
   if (p.polynomial_size == 1024 && p.torus_bits == 64)
     return p.glwe_dimension == 2 && p.pbs_level == 1 && p.pbs_base_log == 23;
-  return wave512_supported(p) || tfhe_lib_instance(p);
+  return wave512_supported(p) || tfhe_lib_instance(p) || wave16k_supported(p);
 }
 
 // every set with an instance gets it by default; the bit-exact kernels stay selectable
-bool wave_default(const camd_params& p) { return wave_supported(p); }
+bool wave_default(const camd_params& p) {
+  static const bool big = []() {
+    const char* e = getenv("CAMD_WAVE_16K");
+    return e ? atoi(e) != 0 : false;
+  }();
+  if (wave16k_supported(p)) return big;
+  return wave_supported(p);
+}
 
-size_t wave_tables_count(uint32_t N) { return N == 512 ? wave512_tables_count() : (size_t)TAB_TOTAL; }
+size_t wave_tables_count(uint32_t N) {
+  return N == 512 ? wave512_tables_count() : N == 16384 ? wave16k_tables_count() : (size_t)TAB_TOTAL;
+}
 
 void wave_fill_tables(uint32_t N, double2* t) {
   if (N == 512) {
     wave512_fill_tables(t);
+    return;
+  }
+  if (N == 16384) {
+    wave16k_fill_tables(t);
     return;
   }
   for (int j = 0; j < 512; j++) {
@@ -1034,6 +1056,10 @@ int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, 
     if ((int)sizeof(T) * 8 != (int)p.torus_bits) return fail(CAMD_EINVAL, "wave kernel: torus width mismatch");
     return wave512_bsk_to_fourier<T>(bsk_std, fbsk, tables, polys, stream);
   }
+  if (wave16k_supported(p)) {
+    if constexpr (sizeof(T) == 8) return wave16k_bsk_to_fourier<T>(bsk_std, fbsk, tables, polys, stream);
+    return fail(CAMD_EINVAL, "wave kernel: torus width mismatch");
+  }
   const size_t lds = TAB_COUNT * sizeof(double2) + WAVES * 2 * PLANE * sizeof(double);
   hipLaunchKernelGGL(wave_bsk_fourier_kernel<T>, dim3((unsigned)((polys + WAVES - 1) / WAVES)), dim3(256), lds, stream,
                      bsk_std, fbsk, tables, polys);
@@ -1045,6 +1071,7 @@ template <typename T>
 int wave_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
   if (a.count == 0) return CAMD_OK;
   if (a.N == 512) return wave512_launch_pbs<T>(a, stream);
+  if (a.N == 16384) return wave16k_launch_pbs<T>(a, stream);
   if constexpr (sizeof(T) == 8) {
     if (a.N == 1024 && a.k == 2 && a.level == 1 && a.base_log == 23) return launch_instance<T, 2, 1, 23>(a, stream);
   } else {

@@ -1,0 +1,665 @@
+// Programmable bootstrap for the largest polynomial size (N = 16384, k = 1, two or three levels):
+// the throughput kernel of the PARAM_MESSAGE_4_CARRY_4 class.
+//
+// Replaces FftEngine::discard_bootstrap_lwe_ciphertext as the reference calls it at
+// concrete-shortint/src/engine/server_side/mod.rs:148-153, for the parameter sets of
+// concrete-shortint/src/parameters/mod.rs:665-808 (N = 16384). Same contract as the other kernels
+// of the wave family: the reference's algorithm with its own order of f64 operations, so
+// decryptions and the noise bound are the reference's and the last bits of a ciphertext are not;
+// the bit-exact kernel for these sets is pbs_block.hip.
+//
+// One 512-thread workgroup (two waves per SIMD) walks one ciphertext through its n CMUXes.
+//   * The 8192-point transform is a four-step one: thread t holds the sixteen points
+//     512 a + t and transforms them in registers (radix 16, the twist folded into its input and
+//     output factors); ONE transposition through a 128 KB LDS image hands wave w the two
+//     512-point sub-transforms 2w and 2w + 1, which run on that wave alone, eight points per
+//     lane, with every lane exchange in registers (v_permlane32_swap, v_permlane16_swap, row
+//     shifts, quad permutes). A transform costs two workgroup barriers, around the
+//     transposition, and 256 KB of LDS traffic.
+//   * The Fourier-domain sums of both output columns stay in registers for the whole CMUX
+//     (2 x 16 complex values per thread); the key (1 MB per CMUX for two levels) streams from
+//     the L2 into the multiply-accumulate of each sub-transform.
+//   * The accumulator is kept to 32 bits per coefficient (the high dwords of the torus words;
+//     digits come from the high dwords anyway, and each CMUX's increment is rounded at 2^-32 of
+//     the torus, orders of magnitude below the output noise) in a per-workgroup slab of 128 KB,
+//     coefficients j and j + N/2 side by side: the rotated difference of a point is two 8-byte
+//     loads, the update one load and one store.
+//   * Signed digits are the balanced ones (each in [-B/2, B/2), lowest level first from a value
+//     rounded to L base_log bits): they represent the same rounded value as the reference's.
+#include "lane_swap.hpp"
+#include "wave1024.hpp"
+
+namespace camd {
+
+namespace {
+
+namespace w16 {
+
+constexpr int N = 16384, M = 8192, LOGN = 14, LOGM = 13;
+constexpr int THREADS = 512, PTS = 16;
+
+// table buffer, in double2 entries: the folded constants of the 512-point sub-transforms (the LDS
+// image of the kernels) and the two per-thread factors of the four-step transform
+constexpr int T_A = 0;                 // [pair 9][lane]: forward, second pass: input q of lane (hi,lo) carries e^{-2 pi i (8q+lo) hi/512}
+constexpr int T_B = T_A + 9 * 64;      // [pair 8][lo]:   input q carries e^{-2 pi i lo q/64}
+constexpr int T_C = T_B + 8 * 8;       // [pair 9][lane]: inverse, third pass: input b carries the conjugate of e^{-2 pi i lane b/512}
+constexpr int T_LDS = T_C + 9 * 64;    // entries staged in LDS
+constexpr int T_W = T_LDS;             // [t]: e^{i pi t/16384}
+constexpr int T_V = T_W + THREADS;     // [t]: e^{-i pi t/4096}
+constexpr int T_TOTAL = T_V + THREADS;
+
+constexpr size_t IMAGE_BYTES = (size_t)PTS * THREADS * sizeof(double2);   // 128 KB
+constexpr size_t LDS_BYTES = T_LDS * sizeof(double2) + IMAGE_BYTES;
+constexpr size_t SLAB_BYTES = 2 * (size_t)N * sizeof(uint32_t);          // accumulator of one ciphertext (k + 1 = 2 polynomials)
+
+// e^{i pi a/32}, a = 0..15: the per-register part of the twist
+__device__ __forceinline__ double2 twist16(int a) {
+  constexpr double C[16] = {1.0, 0.99518472667219688624, 0.98078528040323044913, 0.95694033573220886494,
+                            0.92387953251128675613, 0.88192126434835502971, 0.83146961230254523708, 0.77301045336273696081,
+                            0.70710678118654752440, 0.63439328416364549822, 0.55557023301960222474, 0.47139673682599764856,
+                            0.38268343236508977173, 0.29028467725446236764, 0.19509032201612826785, 0.09801714032956060199};
+  return make_double2(C[a], a == 0 ? 0.0 : C[16 - a]);
+}
+// e^{-2 pi i j/16}
+__device__ __forceinline__ double2 w16(int j) {
+  constexpr double C[5] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173, 0.0};
+  j &= 15;
+  const int q = j >> 2, r = j & 3;                       // angle = -(q * 90 + r * 22.5) degrees
+  const double c = C[r], s = C[4 - r];                   // cos, sin of r * 22.5 degrees
+  // rotate (c, -s) by -q * 90 degrees
+  switch (q) {
+    case 0: return make_double2(c, -s);
+    case 1: return make_double2(-s, -c);
+    case 2: return make_double2(-c, s);
+    default: return make_double2(s, c);
+  }
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(double2& a, double2& b, double2& c, double2& d) {
+  const double2 s0 = cadd(a, c), d0 = csub(a, c), s1 = cadd(b, d), d1 = csub(b, d);
+  const double2 r = INV ? mul_pos_i(d1) : mul_neg_i(d1);
+  a = cadd(s0, s1);
+  c = csub(s0, s1);
+  b = cadd(d0, r);
+  d = csub(d0, r);
+}
+// 16-point DFT in registers, natural order in and out; INV selects e^{+2 pi i jk/16}
+template <bool INV>
+__device__ __forceinline__ void dft16(double2 (&x)[16]) {
+  // a = 4 alpha + beta, k = kappa + 4 lambda
+#pragma unroll
+  for (int beta = 0; beta < 4; beta++) dft4<INV>(x[beta], x[4 + beta], x[8 + beta], x[12 + beta]);   // over alpha: x[4 kappa + beta]
+#pragma unroll
+  for (int kappa = 1; kappa < 4; kappa++)
+#pragma unroll
+    for (int beta = 1; beta < 4; beta++) {
+      const double2 w = w16(beta * kappa);
+      x[4 * kappa + beta] = INV ? cmul_conj(x[4 * kappa + beta], w) : cmul(x[4 * kappa + beta], w);
+    }
+  double2 y[16];
+#pragma unroll
+  for (int kappa = 0; kappa < 4; kappa++) {
+    dft4<INV>(x[4 * kappa], x[4 * kappa + 1], x[4 * kappa + 2], x[4 * kappa + 3]);                  // over beta: lambda
+#pragma unroll
+    for (int lambda = 0; lambda < 4; lambda++) y[kappa + 4 * lambda] = x[4 * kappa + lambda];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) x[k] = y[k];
+}
+
+// ---- lane exchanges of the 512-point sub-transforms, all in registers ----
+// value of a quad permutation of `v` (0x4E: lane ^ 2, 0xB1: lane ^ 1)
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// register bit <-> lane bit PB (1 or 0): the values of lanes with that bit set in `a` trade places
+// with those of lanes with it clear in `b`
+template <int PB>
+__device__ __forceinline__ void swap_words_quad(uint32_t& a, uint32_t& b, bool lane_bit) {
+  constexpr int CTRL = PB == 1 ? 0x4E : 0xB1;
+  const uint32_t fb = quad_perm<CTRL>(b), fa = quad_perm<CTRL>(a);
+  a = lane_bit ? fb : a;
+  b = lane_bit ? b : fa;
+}
+template <int PB>
+__device__ __forceinline__ void swap_complex_quad(double2& a, double2& b, bool lane_bit) {
+  uint32_t a0 = (uint32_t)__double2loint(a.x), a1 = (uint32_t)__double2hiint(a.x);
+  uint32_t a2 = (uint32_t)__double2loint(a.y), a3 = (uint32_t)__double2hiint(a.y);
+  uint32_t b0 = (uint32_t)__double2loint(b.x), b1 = (uint32_t)__double2hiint(b.x);
+  uint32_t b2 = (uint32_t)__double2loint(b.y), b3 = (uint32_t)__double2hiint(b.y);
+  swap_words_quad<PB>(a0, b0, lane_bit); swap_words_quad<PB>(a1, b1, lane_bit);
+  swap_words_quad<PB>(a2, b2, lane_bit); swap_words_quad<PB>(a3, b3, lane_bit);
+  a = make_double2(__hiloint2double((int)a1, (int)a0), __hiloint2double((int)a3, (int)a2));
+  b = make_double2(__hiloint2double((int)b1, (int)b0), __hiloint2double((int)b3, (int)b2));
+}
+// x[q] of lane (h, lo) becomes what x[h] of lane (q, lo) was
+#ifdef W16_DEBUG_NOPS
+#define W16_STAGE_FENCE() asm volatile("s_nop 7\n s_nop 7" ::: "memory")
+#else
+#define W16_STAGE_FENCE()
+#endif
+__device__ __forceinline__ void transpose_5_3(double2 (&x)[8]) {
+  W16_STAGE_FENCE();
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    if (!(r & 4)) swap_complex<5>(x[r], x[r | 4]);
+  W16_STAGE_FENCE();
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    if (!(r & 2)) swap_complex<4>(x[r], x[r | 2]);
+  W16_STAGE_FENCE();
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    if (!(r & 1)) swap_complex<3>(x[r], x[r | 1]);
+  W16_STAGE_FENCE();
+}
+// x[q] of lane (hi, l) becomes what x[l] of lane (hi, q) was
+__device__ __forceinline__ void transpose_2_0(double2 (&x)[8], int lane) {
+  const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+  W16_STAGE_FENCE();
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    if (!(r & 4)) swap_complex<2>(x[r], x[r | 4]);
+  W16_STAGE_FENCE();
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    if (!(r & 2)) swap_complex_quad<1>(x[r], x[r | 2], b1);
+  W16_STAGE_FENCE();
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    if (!(r & 1)) swap_complex_quad<0>(x[r], x[r | 1], b0);
+  W16_STAGE_FENCE();
+}
+
+// 512-point transform on one wave: x[a] = point 64 a + lane in, x[g] = X[64 g + 8 (lane & 7) + (lane >> 3)] out
+__device__ __forceinline__ void fft512_plain_forward(double2 (&x)[8], int lane, const double2* tab) {
+#ifdef W16_DEBUG_NO_FFT512
+  return;
+#endif
+  dft8<false>(x);
+  transpose_5_3(x);
+  {
+    const Tw8 k = load_tw8<true>(tab + T_A + lane, 64);
+    dft8_tw<false, true>(x, k);
+  }
+  transpose_2_0(x, lane);
+  {
+    const Tw8 k = load_tw8<false>(tab + T_B + (lane & 7), 8);
+    dft8_tw<false, false>(x, k);
+  }
+}
+// unnormalised inverse: spectrum in the order above in, x[a] = 512 * point (64 a + lane) out
+__device__ __forceinline__ void fft512_plain_inverse(double2 (&x)[8], int lane, const double2* tab) {
+#ifdef W16_DEBUG_NO_FFT512
+  return;
+#endif
+  dft8<true>(x);
+  transpose_2_0(x, lane);
+  {
+    const Tw8 k = load_tw8<false>(tab + T_B + (lane & 7), 8);
+    dft8_tw<true, false>(x, k);
+  }
+  transpose_5_3(x);
+  {
+    const Tw8 k = load_tw8<false>(tab + T_C + lane, 64);
+    dft8_tw<true, false>(x, k);
+  }
+}
+
+// The factors of the sixteen outputs of a thread's radix-16 step are f[k1] = w v^k1 with
+// w = e^{i pi t/16384} (the thread's share of the twist) and v = e^{-i pi t/4096} (the twiddle of the
+// four-step transform). They are formed four at a time, f[j + 4m] = (w v^j) (v^4)^m, so that only
+// five of them are alive at once and no power is more than six products deep.
+template <bool CONJ>
+__device__ __forceinline__ void apply_step_factors(double2 (&z)[16], double2 w, double2 v) {
+  const double2 v2 = cmul(v, v), v4 = cmul(v2, v2);
+  double2 b[4];
+  b[0] = w; b[1] = cmul(w, v); b[2] = cmul(w, v2); b[3] = cmul(b[1], v2);
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      z[j + 4 * m] = CONJ ? cmul_conj(z[j + 4 * m], b[j]) : cmul(z[j + 4 * m], b[j]);
+      if (m < 3) b[j] = cmul(b[j], v4);
+    }
+  }
+}
+
+// First half of the forward transform: z[a] = point 512 a + t (untwisted) in; out: the sixteen
+// values Y[k1] that go to row k1 of the transposition image.
+__device__ __forceinline__ void forward_step1(double2 (&z)[16], double2 w, double2 v) {
+#ifdef W16_DEBUG_NO_STEP
+  return;
+#endif
+#pragma unroll
+  for (int a = 1; a < 16; a++) z[a] = cmul(z[a], twist16(a));
+  dft16<false>(z);
+  apply_step_factors<false>(z, w, v);
+}
+// Last half of the inverse transform: the sixteen values of image column t in, z[a] = 8192 *
+// (coefficient 512 a + t, coefficient 512 a + t + 8192) out (the key carries the 1/8192).
+__device__ __forceinline__ void inverse_step2(double2 (&z)[16], double2 w, double2 v) {
+#ifdef W16_DEBUG_NO_STEP
+  return;
+#endif
+  apply_step_factors<true>(z, w, v);
+  dft16<true>(z);
+#pragma unroll
+  for (int a = 1; a < 16; a++) z[a] = cmul_conj(z[a], twist16(a));
+}
+
+// ---- key conversion: one workgroup per polynomial; spectrum in the order the bootstrap reads it:
+// [wave w][sub-transform e][register g][lane], frequency (2w + e) + 16 (64 g + 8 (lane & 7) + (lane >> 3)),
+// values scaled by 1/8192 ----
+template <typename T>
+__global__ __launch_bounds__(THREADS) void bsk_fourier_kernel(const T* __restrict__ bsk, double2* __restrict__ out,
+                                                              const double2* __restrict__ tables, size_t polys) {
+  using S = typename Torus<T>::Signed;
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  double2* img = (double2*)(smem + T_LDS * sizeof(double2));
+  for (int i = threadIdx.x; i < T_LDS; i += THREADS) tab[i] = tables[i];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const T* poly = bsk + (size_t)blockIdx.x * N;
+  const double scale = 0x1.0p-64;
+  double2 z[16];
+#pragma unroll
+  for (int a = 0; a < 16; a++) {
+    const int j = 512 * a + t;
+    z[a] = make_double2(signed_to_double((S)poly[j]) * scale, signed_to_double((S)poly[j + M]) * scale);
+  }
+  forward_step1(z, tables[T_W + t], tables[T_V + t]);
+#pragma unroll
+  for (int k = 0; k < 16; k++) img[k * THREADS + t] = z[k];
+  __syncthreads();
+  double2* dst = out + (size_t)blockIdx.x * M + (size_t)wave * 1024;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    double2 x[8];
+#pragma unroll
+    for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
+    fft512_plain_forward(x, lane, tab);
+#pragma unroll
+    for (int g = 0; g < 8; g++) dst[(e * 8 + g) * 64 + lane] = make_double2(x[g].x * (1.0 / M), x[g].y * (1.0 / M));
+  }
+}
+
+// position of coefficient j in a polynomial of the slab: j and j + N/2 side by side
+__device__ __forceinline__ uint32_t slab_index(uint32_t j) { return ((j & (M - 1)) << 1) | (j >> LOGM); }
+
+#ifdef W16_DEBUG_KERNELS
+__device__ double2 dump_digits[M], dump_sums[M], dump_back[M];
+#endif
+
+template <typename T, int L, int BL>
+__global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
+  static_assert(sizeof(T) == 8 && BL * L <= 30, "64-bit torus whose digits lie in the high dword");
+  constexpr int R = 2;                    // k + 1
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  double2* img = (double2*)(smem + T_LDS * sizeof(double2));
+  for (int i = threadIdx.x; i < T_LDS; i += THREADS) tab[i] = a.tables[i];
+  __syncthreads();
+
+  const int t0 = threadIdx.x;
+  int t = t0;
+  uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * SLAB_BYTES);   // [R][N] paired layout
+  const double2 fw = a.tables[T_W + t0], fv = a.tables[T_V + t0];
+  const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.fbsk, 0, (int)0x7FFFFFFF, 0x00020000);   // offsets are formed per iteration: the base moves with it
+  const uint32_t n = a.n;
+
+  for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
+    const T* in = a.ct_in + ct * a.in_stride;
+    const uint32_t lut_id = checked_lut_id(a, ct);
+    const T* lut = a.luts + (size_t)lut_id * (R * N);
+    {
+      // acc <- lut * X^{-b_hat}, high dwords
+      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+      const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
+      for (int idx = t0; idx < R * N; idx += THREADS) {
+        const int c = idx >> LOGN, j = idx & (N - 1);
+        acc[c * N + slab_index(j)] = (uint32_t)(rotated_coeff<T>(lut + (size_t)c * N, j, d0, N) >> 32);
+      }
+    }
+    __syncthreads();
+
+    for (uint32_t i = 0; i < n; i++) {
+      const T a_i = wave_uniform(in[i]);
+      if (a_i == 0) continue;            // the reference skips these iterations too
+      // thread index made opaque once per CMUX: addresses are recomputed, not hoisted and spilled
+      t = t0;
+      asm volatile("" : "+v"(t));
+      const int lane = t & 63, wave = t >> 6;
+      const uint32_t a_hat = modswitch<T>(a_i, LOGN) & (2 * N - 1);
+      // key of this iteration: [level][row][column][8192] complex; per-lane part of every key address
+      const uint32_t key_lane = (uint32_t)lane * 16u + (uint32_t)wave * 16384u;
+
+      double2 S[R][2][8];   // Fourier sums: [column][sub-transform][register]
+#pragma unroll
+      for (int c = 0; c < R; c++)
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+          for (int g = 0; g < 8; g++) S[c][e][g] = make_double2(0.0, 0.0);
+
+#pragma unroll 1
+      for (int r = 0; r < R; r++) {
+        // gather the rotated difference of row r: 16 points = 32 coefficients; balanced digits, lowest level first
+        // the two states of a point share a register once what is left of them fits 16 bits each
+        // (after the first digit of a two-level decomposition of at most 15 bits per level)
+        constexpr bool PACK = (L == 2 && BL <= 15);
+        double2 zlow[PACK ? 16 : 1];   // digits of level L when they are taken at gather time
+        int32_t st0[16], st1[PACK ? 1 : 16];
+        const uint32_t* p = acc + r * N;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const uint32_t j0 = 512 * q + t;                                   // and j0 + M
+          const uint2 own = *(const uint2*)(p + 2 * j0);
+          const uint32_t s0 = (j0 - a_hat) & (2 * N - 1);                     // rotated index of j0; that of j0 + M is s0 + M
+          const uint2 pr = *(const uint2*)(p + 2 * (s0 & (M - 1)));
+          const bool hi_half = (s0 & M) != 0;
+          uint32_t r0 = hi_half ? pr.y : pr.x, r1 = hi_half ? pr.x : pr.y;   // coefficients s0 mod N and (s0 + M) mod N
+          const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)s0, LOGN, 1);
+          const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(s0 + M), LOGN, 1);
+          constexpr uint32_t HALF = 1u << (32 - BL * L - 1);
+          // ((rot ^ m) - own) rounded to the top BL L bits, as a signed value
+          const int32_t v0 = (int32_t)(((r0 ^ m0) + HALF) - own.x) >> (32 - BL * L);
+          const int32_t v1 = (int32_t)(((r1 ^ m1) + HALF) - own.y) >> (32 - BL * L);
+          if constexpr (PACK) {
+            // lowest digits now (they go to level L), remainders packed for level 1
+            const int32_t e0 = __builtin_amdgcn_sbfe(v0, 0, BL), e1 = __builtin_amdgcn_sbfe(v1, 0, BL);
+            zlow[q] = make_double2((double)e0, (double)e1);
+            const int32_t h0 = (v0 - e0) >> BL, h1 = (v1 - e1) >> BL;      // each in [-2^(BL-1), 2^(BL-1)]
+            st0[q] = (int32_t)(((uint32_t)h1 << 16) | ((uint32_t)h0 & 0xFFFFu));
+          } else {
+            st0[q] = v0;
+            st1[q] = v1;
+          }
+        }
+#pragma unroll
+        for (int l = L; l >= 1; l--) {
+          double2 z[16];
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            if constexpr (PACK) {
+              if (l == L)
+                z[q] = zlow[q];
+              else
+                z[q] = make_double2((double)(int32_t)__builtin_amdgcn_sbfe(st0[q], 0, 16), (double)(st0[q] >> 16));   // the builtin's result type is unsigned
+            } else {
+              int32_t d0, d1;
+              if (l > 1) {
+                d0 = __builtin_amdgcn_sbfe(st0[q], 0, BL);
+                d1 = __builtin_amdgcn_sbfe(st1[q], 0, BL);
+                st0[q] = (st0[q] - d0) >> BL;
+                st1[q] = (st1[q] - d1) >> BL;
+              } else {
+                d0 = st0[q];
+                d1 = st1[q];
+              }
+              z[q] = make_double2((double)d0, (double)d1);
+            }
+          }
+#ifdef W16_DEBUG_KERNELS
+          if (blockIdx.x == 0 && i == 0 && r == 0 && l == 1)
+            for (int q = 0; q < 16; q++) dump_digits[512 * q + t] = z[q];
+#endif
+          forward_step1(z, fw, fv);
+          __syncthreads();               // everyone is done with the image's previous content
+#pragma unroll
+          for (int k = 0; k < 16; k++) img[k * THREADS + t] = z[k];
+          __syncthreads();
+          // the two sub-transforms of this wave, one after the other, each followed by its products
+          const uint32_t key_base = (uint32_t)(((size_t)i * L + (l - 1)) * R + r) * (uint32_t)(R * M * sizeof(double2));
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            double2 x[8];
+#pragma unroll
+            for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
+            fft512_plain_forward(x, lane, tab);
+            __builtin_amdgcn_sched_barrier(0);
+            double2 kq[R][8];
+#pragma unroll
+            for (int c = 0; c < R; c++)
+#pragma unroll
+              for (int g = 0; g < 8; g++) {
+                const auto w = __builtin_amdgcn_raw_buffer_load_b128(
+                    key_rsrc, (int)(key_lane + (g & 3) * 1024),
+                    (int)(key_base + (uint32_t)c * (uint32_t)(M * sizeof(double2)) + e * 8192 + (g >> 2) * 4096), 0);
+                kq[c][g] = as_double2(__builtin_bit_cast(v4u, w));
+              }
+#pragma unroll
+            for (int c = 0; c < R; c++)
+#pragma unroll
+              for (int g = 0; g < 8; g++) S[c][e][g] = cfma(kq[c][g], x[g], S[c][e][g]);
+          }
+        }
+      }
+
+      // back: per column, the two inverse sub-transforms of this wave, the transposition, the radix-16 step, the update
+#pragma unroll 1
+      for (int c = 0; c < R; c++) {
+        __syncthreads();                 // everyone is done with the image's previous content
+#ifdef W16_DEBUG_KERNELS
+        if (blockIdx.x == 0 && i == 0 && c == 0)
+          for (int e = 0; e < 2; e++)
+            for (int g = 0; g < 8; g++) dump_sums[wave * 1024 + (e * 8 + g) * 64 + lane] = S[c][e][g];
+#endif
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          fft512_plain_inverse(S[c][e], lane, tab);
+#pragma unroll
+          for (int g = 0; g < 8; g++) img[(2 * wave + e) * THREADS + 64 * g + lane] = S[c][e][g];
+        }
+        __syncthreads();
+        double2 z[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) z[k] = img[k * THREADS + t];
+        inverse_step2(z, fw, fv);
+#ifdef W16_DEBUG_KERNELS
+        if (blockIdx.x == 0 && i == 0 && c == 0)
+          for (int q = 0; q < 16; q++) dump_back[512 * q + t] = z[q];
+#endif
+        uint32_t* pc = acc + c * N;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const uint32_t j0 = 512 * q + t;
+          uint2 old = *(const uint2*)(pc + 2 * j0);
+          old.x = torus_accumulate(old.x, z[q].x);
+          old.y = torus_accumulate(old.y, z[q].y);
+          *(uint2*)(pc + 2 * j0) = old;
+        }
+      }
+      __syncthreads();                   // the next gather reads what other threads just wrote
+    }
+
+    // sample extraction of coefficient 0; the low dwords are zero
+    T* out = a.ct_out + ct * a.out_stride;
+    for (int j = t0; j < N; j += THREADS) {
+      const uint32_t w = (j == 0) ? acc[slab_index(0)] : (uint32_t)(0u - acc[slab_index(N - j)]);
+      out[j] = (T)w << 32;
+    }
+    if (t0 == 0) out[N] = (T)acc[N + slab_index(0)] << 32;
+    __syncthreads();                     // the slab is rewritten by the next ciphertext
+  }
+}
+
+#ifdef W16_DEBUG_KERNELS
+// transform pieces on their own, for checks against a host transform (debug builds only)
+__global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2* in, double2* out, const double2* tables) {
+  extern __shared__ __align__(16) char smem[];
+  double2* tab = (double2*)smem;
+  double2* img = (double2*)(smem + T_LDS * sizeof(double2));
+  for (int i = threadIdx.x; i < T_LDS; i += THREADS) tab[i] = tables[i];
+  __syncthreads();
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double2 fw = tables[T_W + t], fv = tables[T_V + t];
+  if (mode == 1 || mode == 2) {
+    double2 x[8];
+#pragma unroll
+    for (int g = 0; g < 8; g++) x[g] = in[wave * 512 + 64 * g + lane];
+    if (mode == 1) fft512_plain_forward(x, lane, tab); else fft512_plain_inverse(x, lane, tab);
+#pragma unroll
+    for (int g = 0; g < 8; g++) out[wave * 512 + 64 * g + lane] = x[g];
+  } else if (mode == 3) {
+    double2 z[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) z[a] = in[512 * a + t];
+    forward_step1(z, fw, fv);
+#pragma unroll
+    for (int k = 0; k < 16; k++) img[k * THREADS + t] = z[k];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      double2 x[8];
+#pragma unroll
+      for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
+      fft512_plain_forward(x, lane, tab);
+#pragma unroll
+      for (int g = 0; g < 8; g++) out[wave * 1024 + (e * 8 + g) * 64 + lane] = x[g];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      double2 x[8];
+#pragma unroll
+      for (int g = 0; g < 8; g++) x[g] = in[wave * 1024 + (e * 8 + g) * 64 + lane];
+      fft512_plain_inverse(x, lane, tab);
+#pragma unroll
+      for (int g = 0; g < 8; g++) img[(2 * wave + e) * THREADS + 64 * g + lane] = x[g];
+    }
+    __syncthreads();
+    double2 z[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) z[k] = img[k * THREADS + t];
+    inverse_step2(z, fw, fv);
+#pragma unroll
+    for (int a = 0; a < 16; a++) out[512 * a + t] = z[a];
+  }
+}
+#endif
+
+}  // namespace w16
+
+}  // namespace
+
+bool wave16k_supported(const camd_params& p) {
+  return p.torus_bits == 64 && p.polynomial_size == 16384 && p.glwe_dimension == 1 &&
+         p.pbs_level == 2 && p.pbs_base_log == 15;
+}
+size_t wave16k_tables_count() { return (size_t)w16::T_TOTAL; }
+size_t wave16k_scratch_bytes(unsigned* grid_out, size_t count, int cus) {
+  const unsigned grid = (unsigned)std::min<size_t>(count, (size_t)(cus > 0 ? cus : 1));
+  if (grid_out) *grid_out = grid;
+  return (size_t)grid * w16::SLAB_BYTES;
+}
+
+void wave16k_fill_tables(double2* t) {
+  // folded constants of a twiddled radix-8 pass (dft8_tw in wave1024.hpp): th[q] is the angle of input q
+  auto fold = [&](double2* dst, int stride, const double (&th)[8], bool own_w0) {
+    double c[8], tn[8];
+    for (int q = 0; q < 8; q++) {
+      c[q] = std::cos(th[q]);
+      const double sn = std::sin(th[q]);
+      if (std::fabs(c[q]) < 1e-9) c[q] = 0x1.0p-60;   // a quarter turn: finite tangent, value off by 2^-60
+      tn[q] = sn / c[q];
+    }
+    dst[0 * stride] = make_double2(tn[1], tn[2]);
+    dst[1 * stride] = make_double2(tn[3], tn[4]);
+    dst[2 * stride] = make_double2(tn[5], tn[6]);
+    dst[3 * stride] = make_double2(tn[7], c[4]);
+    dst[4 * stride] = make_double2(c[5] / c[1], c[6] / c[2]);
+    dst[5 * stride] = make_double2(c[7] / c[3], c[2]);
+    dst[6 * stride] = make_double2(c[3] / c[1], c[1]);
+    dst[7 * stride] = make_double2(c[1] * HALF_SQRT2, 0.0);
+    if (own_w0) dst[8 * stride] = make_double2(std::cos(th[0]), std::sin(th[0]));
+  };
+  for (int lane = 0; lane < 64; lane++) {
+    const int hi = lane >> 3, lo = lane & 7;
+    double th[8];
+    for (int q = 0; q < 8; q++) th[q] = -2.0 * M_PI * (double)((8 * q + lo) * hi) / 512.0;
+    fold(t + w16::T_A + lane, 64, th, true);
+    for (int b = 0; b < 8; b++) th[b] = -2.0 * M_PI * (double)(lane * b) / 512.0;
+    fold(t + w16::T_C + lane, 64, th, true);
+  }
+  for (int lo = 0; lo < 8; lo++) {
+    double th[8];
+    for (int q = 0; q < 8; q++) th[q] = -2.0 * M_PI * (double)(lo * q) / 64.0;
+    fold(t + w16::T_B + lo, 8, th, false);
+  }
+  for (int i = 0; i < w16::THREADS; i++) {
+    const double aw = M_PI * (double)i / 16384.0, av = -M_PI * (double)i / 4096.0;
+    t[w16::T_W + i] = make_double2(std::cos(aw), std::sin(aw));
+    t[w16::T_V + i] = make_double2(std::cos(av), std::sin(av));
+  }
+}
+
+template <typename T>
+int wave16k_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream) {
+  auto kern = w16::bsk_fourier_kernel<T>;
+  CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::LDS_BYTES));
+  hipLaunchKernelGGL(kern, dim3((unsigned)polys), dim3(w16::THREADS), w16::LDS_BYTES, stream, bsk_std, fbsk, tables, polys);
+  CAMD_HIP(hipGetLastError());
+  return CAMD_OK;
+}
+
+template <typename T>
+int wave16k_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
+  if constexpr (sizeof(T) == 8) {
+    if (a.count == 0) return CAMD_OK;
+    if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel (N = 16384): the accumulator slabs were not reserved");
+    int dev = 0, cus = 0;
+    CAMD_HIP(hipGetDevice(&dev));
+    CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    unsigned grid = 1;
+    wave16k_scratch_bytes(&grid, a.count, cus);
+    static_assert(w16::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+    if (a.N == 16384 && a.k == 1 && a.level == 2 && a.base_log == 15) {
+      auto kern = w16::pbs_kernel<T, 2, 15>;
+      CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(w16::THREADS), w16::LDS_BYTES, stream, a);
+      CAMD_HIP(hipGetLastError());
+      return CAMD_OK;
+    }
+  }
+  return fail(CAMD_EINVAL, "wave kernel (N = 16384): no instance for this parameter set");
+}
+
+template int wave16k_bsk_to_fourier<uint64_t>(const uint64_t*, double2*, const double2*, size_t, hipStream_t);
+template int wave16k_launch_pbs<uint64_t>(const PbsLaunch<uint64_t>&, hipStream_t);
+template int wave16k_launch_pbs<uint32_t>(const PbsLaunch<uint32_t>&, hipStream_t);
+
+#ifdef W16_DEBUG_KERNELS
+extern "C" int camd_debug_w16_dump(int which, double* out_host) {
+  const size_t bytes = (size_t)w16::M * sizeof(double2);
+  CAMD_HIP(hipDeviceSynchronize());
+  if (which == 0) CAMD_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w16::dump_digits), bytes));
+  if (which == 1) CAMD_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w16::dump_sums), bytes));
+  if (which == 2) CAMD_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w16::dump_back), bytes));
+  return CAMD_OK;
+}
+extern "C" int camd_debug_w16(int mode, const double* in_host, double* out_host) {
+  std::vector<double2> tables(w16::T_TOTAL);
+  wave16k_fill_tables(tables.data());
+  double2 *d_in = nullptr, *d_out = nullptr, *d_tab = nullptr;
+  const size_t bytes = (size_t)w16::M * sizeof(double2);
+  CAMD_HIP(hipMalloc(&d_in, bytes));
+  CAMD_HIP(hipMalloc(&d_out, bytes));
+  CAMD_HIP(hipMalloc(&d_tab, tables.size() * sizeof(double2)));
+  CAMD_HIP(hipMemcpy(d_in, in_host, bytes, hipMemcpyHostToDevice));
+  CAMD_HIP(hipMemcpy(d_tab, tables.data(), tables.size() * sizeof(double2), hipMemcpyHostToDevice));
+  auto kern = w16::debug_kernel;
+  CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::LDS_BYTES));
+  hipLaunchKernelGGL(kern, dim3(1), dim3(w16::THREADS), w16::LDS_BYTES, 0, mode, d_in, d_out, d_tab);
+  CAMD_HIP(hipGetLastError());
+  CAMD_HIP(hipDeviceSynchronize());
+  CAMD_HIP(hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost));
+  hipFree(d_in); hipFree(d_out); hipFree(d_tab);
+  return CAMD_OK;
+}
+#endif
+
+}  // namespace camd

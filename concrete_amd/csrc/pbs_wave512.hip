@@ -688,7 +688,7 @@ int launch(const PbsLaunch<T>& a, hipStream_t stream) {
   const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // one wave per SIMD (512 registers)
   if (persistent < grid) {
     if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
-    CAMD_HIP(hipMemsetAsync(a.scratch, 0, wave_scratch_bytes(), stream));
+    CAMD_HIP(hipMemsetAsync(a.scratch, 0, RENDEZVOUS_BYTES, stream));
   }
   hipLaunchKernelGGL(kern, dim3(persistent), dim3(256), lds, stream, a);
   CAMD_HIP(hipGetLastError());

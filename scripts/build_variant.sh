@@ -6,7 +6,7 @@
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
-ALL="abi.hip keyswitch.hip keyswitch_mfma.hip linear.hip pbs_generic.hip pbs_block.hip pbs_wave.hip pbs_wave8.hip pbs_wave512.hip probe.hip client.cpp"
+ALL="abi.hip keyswitch.hip keyswitch_mfma.hip linear.hip pbs_generic.hip pbs_block.hip pbs_wave.hip pbs_wave8.hip pbs_wave16k.hip pbs_wave512.hip probe.hip client.cpp"
 SRCS=${VARIANT_SOURCES:-$ALL}
 mkdir -p $ROOT/build/obj_$NAME
 cd $ROOT/concrete_amd/csrc

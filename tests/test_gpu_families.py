@@ -383,6 +383,41 @@ def test_largest_polynomial_full_size_bit_exact(gpu_ctx, pname, count):
     dk.close()
 
 
+@pytest.mark.parametrize("n", [1, 7])
+def test_wave_kernel_largest_polynomial_short(gpu_ctx, n):
+    """The throughput kernel of the N = 16384 class (pbs_wave16k.hip) on a shortened LWE dimension:
+    one CMUX pins the transform, the key layout and the digits against the oracle almost word for
+    word (the f64 results differ in their last bits only, and nothing has diverged yet); a few
+    CMUXes must decrypt like the oracle with a phase error far inside the decoding margin."""
+    p = P.SHORTINT_BY_NAME["PARAM_MESSAGE_4_CARRY_4"]
+    ks = get_keys(p, 64, n_override=n)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    assert dk.variant == CAMD_PBS_WAVE
+    msg, sup = p.message_modulus, p.message_modulus * p.carry_modulus
+    fs = [lambda x: x % msg, lambda x: x // msg]
+    luts = [o.generate_accumulator(f) for f in fs]
+    for l in luts:
+        dk.upload_lut(l)
+    delta = O.shortint_delta(p)
+    count = 12
+    msgs = [0, 1, msg - 1, msg, sup // 2 - 1, sup // 2, sup - 1] + [(37 * i + 5) % sup for i in range(count - 7)]
+    cts = np.stack([o.lwe_encrypt(ks.rng, ks.glwe, m * delta, ks.lwe_std) for m in msgs])
+    ids = (np.arange(count) % 2).astype(np.uint32)
+    got = dk.ks_pbs(cts, ids)
+    want = o.ks_pbs_batch(ks.ksk, ks.fbsk, np.concatenate(luts), ids, cts, threads=8)
+    diff = np.abs((got - want).view(np.int64).astype(np.float64)) / 2.0 ** 64
+    print(f"n = {n}: largest word difference from the oracle {diff.max():.3e} of the torus")
+    if n == 1:
+        assert diff.max() < 2.0 ** -28        # rounding of the accumulator to 2^-32 plus the f64 transforms
+    for i in range(count):
+        pg, pw = o.lwe_phase(ks.glwe, got[i]), o.lwe_phase(ks.glwe, want[i])
+        assert O.shortint_decode(p, pg) == O.shortint_decode(p, pw), i
+        err = ((pg - pw + 2 ** 63) % 2 ** 64 - 2 ** 63) / float(delta)
+        assert abs(err) < 0.05, (i, err)
+    dk.close()
+
+
 @pytest.mark.parametrize("pname,bits", [("PARAM_MESSAGE_1_CARRY_1", 64), ("PARAM_MESSAGE_4_CARRY_4", 64),
                                         ("PARAM_MESSAGE_1_CARRY_7", 64), ("DEFAULT_PARAMETERS", 32), ("TFHE_LIB_PARAMETERS", 32)])
 def test_matrix_core_keyswitch_every_torus_and_decomposition(gpu_ctx, pname, bits, monkeypatch):
