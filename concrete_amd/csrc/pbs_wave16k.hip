@@ -304,9 +304,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   __syncthreads();
 
   const int t0 = threadIdx.x;
-  int t = t0;
   uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * SLAB_BYTES);   // [R][N] paired layout
-  const double2 fw = a.tables[T_W + t0], fv = a.tables[T_V + t0];
   const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.fbsk, 0, (int)0x7FFFFFFF, 0x00020000);   // offsets are formed per iteration: the base moves with it
   const uint32_t n = a.n;
@@ -329,13 +327,8 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
     for (uint32_t i = 0; i < n; i++) {
       const T a_i = wave_uniform(in[i]);
       if (a_i == 0) continue;            // the reference skips these iterations too
-      // thread index made opaque once per CMUX: addresses are recomputed, not hoisted and spilled
-      t = t0;
-      asm volatile("" : "+v"(t));
-      const int lane = t & 63, wave = t >> 6;
       const uint32_t a_hat = modswitch<T>(a_i, LOGN) & (2 * N - 1);
-      // key of this iteration: [level][row][column][8192] complex; per-lane part of every key address
-      const uint32_t key_lane = (uint32_t)lane * 16u + (uint32_t)wave * 16384u;
+      // key of this iteration: [level][row][column][8192] complex
 
       double2 S[R][2][8];   // Fourier sums: [column][sub-transform][register]
 #pragma unroll
@@ -347,67 +340,52 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
 
 #pragma unroll 1
       for (int r = 0; r < R; r++) {
-        // gather the rotated difference of row r: 16 points = 32 coefficients; balanced digits, lowest level first
-        // the two states of a point share a register once what is left of them fits 16 bits each
-        // (after the first digit of a two-level decomposition of at most 15 bits per level)
-        constexpr bool PACK = (L == 2 && BL <= 15);
-        double2 zlow[PACK ? 16 : 1];   // digits of level L when they are taken at gather time
-        int32_t st0[16], st1[PACK ? 1 : 16];
+        // The rotated difference of row r is gathered once per level (16 points = 32 coefficients, from the
+        // L1/L2-resident slab) instead of keeping decomposition states alive across a transform: the sums
+        // already take half of the register file. Balanced digits, lowest level first.
         const uint32_t* p = acc + r * N;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const uint32_t j0 = 512 * q + t;                                   // and j0 + M
-          const uint2 own = *(const uint2*)(p + 2 * j0);
-          const uint32_t s0 = (j0 - a_hat) & (2 * N - 1);                     // rotated index of j0; that of j0 + M is s0 + M
-          const uint2 pr = *(const uint2*)(p + 2 * (s0 & (M - 1)));
-          const bool hi_half = (s0 & M) != 0;
-          uint32_t r0 = hi_half ? pr.y : pr.x, r1 = hi_half ? pr.x : pr.y;   // coefficients s0 mod N and (s0 + M) mod N
-          const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)s0, LOGN, 1);
-          const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(s0 + M), LOGN, 1);
-          constexpr uint32_t HALF = 1u << (32 - BL * L - 1);
-          // ((rot ^ m) - own) rounded to the top BL L bits, as a signed value
-          const int32_t v0 = (int32_t)(((r0 ^ m0) + HALF) - own.x) >> (32 - BL * L);
-          const int32_t v1 = (int32_t)(((r1 ^ m1) + HALF) - own.y) >> (32 - BL * L);
-          if constexpr (PACK) {
-            // lowest digits now (they go to level L), remainders packed for level 1
-            const int32_t e0 = __builtin_amdgcn_sbfe(v0, 0, BL), e1 = __builtin_amdgcn_sbfe(v1, 0, BL);
-            zlow[q] = make_double2((double)e0, (double)e1);
-            const int32_t h0 = (v0 - e0) >> BL, h1 = (v1 - e1) >> BL;      // each in [-2^(BL-1), 2^(BL-1)]
-            st0[q] = (int32_t)(((uint32_t)h1 << 16) | ((uint32_t)h0 & 0xFFFFu));
-          } else {
-            st0[q] = v0;
-            st1[q] = v1;
-          }
-        }
-#pragma unroll
         for (int l = L; l >= 1; l--) {
+          // the thread index is made opaque per transform: indices that do not change from one gather to the
+          // next are recomputed then, where hoisting them would cost registers that are not there
+          int t = t0;
+          asm volatile("" : "+v"(t));
+          const int lane = t & 63, wave = t >> 6;
+          const uint32_t key_lane = (uint32_t)lane * 16u + (uint32_t)wave * 16384u;
           double2 z[16];
 #pragma unroll
           for (int q = 0; q < 16; q++) {
-            if constexpr (PACK) {
-              if (l == L)
-                z[q] = zlow[q];
-              else
-                z[q] = make_double2((double)(int32_t)__builtin_amdgcn_sbfe(st0[q], 0, 16), (double)(st0[q] >> 16));   // the builtin's result type is unsigned
-            } else {
-              int32_t d0, d1;
-              if (l > 1) {
-                d0 = __builtin_amdgcn_sbfe(st0[q], 0, BL);
-                d1 = __builtin_amdgcn_sbfe(st1[q], 0, BL);
-                st0[q] = (st0[q] - d0) >> BL;
-                st1[q] = (st1[q] - d1) >> BL;
-              } else {
-                d0 = st0[q];
-                d1 = st1[q];
-              }
-              z[q] = make_double2((double)d0, (double)d1);
+            const uint32_t j0 = 512 * q + t;                                   // and j0 + M
+            const uint2 own = *(const uint2*)(p + 2 * j0);
+            const uint32_t s0 = (j0 - a_hat) & (2 * N - 1);                     // rotated index of j0; that of j0 + M is s0 + M
+            const uint2 pr = *(const uint2*)(p + 2 * (s0 & (M - 1)));
+            const bool hi_half = (s0 & M) != 0;
+            uint32_t r0 = hi_half ? pr.y : pr.x, r1 = hi_half ? pr.x : pr.y;   // coefficients s0 mod N and (s0 + M) mod N
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)s0, LOGN, 1);
+            const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(s0 + M), LOGN, 1);
+            constexpr uint32_t HALF = 1u << (32 - BL * L - 1);
+            // ((rot ^ m) - own) rounded to the top BL L bits, as a signed value
+            int32_t v0 = (int32_t)(((r0 ^ m0) + HALF) - own.x) >> (32 - BL * L);
+            int32_t v1 = (int32_t)(((r1 ^ m1) + HALF) - own.y) >> (32 - BL * L);
+#pragma unroll
+            for (int m = L; m > l; m--) {                                        // strip the digits below level l
+              v0 = (v0 - (int32_t)__builtin_amdgcn_sbfe(v0, 0, BL)) >> BL;
+              v1 = (v1 - (int32_t)__builtin_amdgcn_sbfe(v1, 0, BL)) >> BL;
             }
+            if (l > 1) {
+              v0 = (int32_t)__builtin_amdgcn_sbfe(v0, 0, BL);
+              v1 = (int32_t)__builtin_amdgcn_sbfe(v1, 0, BL);
+            }
+            z[q] = make_double2((double)v0, (double)v1);
+            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four points' loads in flight at a time: registers are short
           }
 #ifdef W16_DEBUG_KERNELS
           if (blockIdx.x == 0 && i == 0 && r == 0 && l == 1)
             for (int q = 0; q < 16; q++) dump_digits[512 * q + t] = z[q];
 #endif
-          forward_step1(z, fw, fv);
+          __builtin_amdgcn_sched_barrier(0);
+          forward_step1(z, a.tables[T_W + t], a.tables[T_V + t]);
+          __builtin_amdgcn_sched_barrier(0);
           __syncthreads();               // everyone is done with the image's previous content
 #pragma unroll
           for (int k = 0; k < 16; k++) img[k * THREADS + t] = z[k];
@@ -421,27 +399,30 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
             fft512_plain_forward(x, lane, tab);
             __builtin_amdgcn_sched_barrier(0);
-            double2 kq[R][8];
 #pragma unroll
-            for (int c = 0; c < R; c++)
+            for (int c = 0; c < R; c++) {      // one column at a time: eight key values in flight, not sixteen
+              double2 kq[8];
 #pragma unroll
               for (int g = 0; g < 8; g++) {
                 const auto w = __builtin_amdgcn_raw_buffer_load_b128(
                     key_rsrc, (int)(key_lane + (g & 3) * 1024),
                     (int)(key_base + (uint32_t)c * (uint32_t)(M * sizeof(double2)) + e * 8192 + (g >> 2) * 4096), 0);
-                kq[c][g] = as_double2(__builtin_bit_cast(v4u, w));
+                kq[g] = as_double2(__builtin_bit_cast(v4u, w));
               }
 #pragma unroll
-            for (int c = 0; c < R; c++)
-#pragma unroll
-              for (int g = 0; g < 8; g++) S[c][e][g] = cfma(kq[c][g], x[g], S[c][e][g]);
+              for (int g = 0; g < 8; g++) S[c][e][g] = cfma(kq[g], x[g], S[c][e][g]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
       }
 
       // back: per column, the two inverse sub-transforms of this wave, the transposition, the radix-16 step, the update
-#pragma unroll 1
+#pragma unroll                        // a run-time column index would put the sums in scratch memory
       for (int c = 0; c < R; c++) {
+        int t = t0;
+        asm volatile("" : "+v"(t));
+        const int lane = t & 63, wave = t >> 6;
         __syncthreads();                 // everyone is done with the image's previous content
 #ifdef W16_DEBUG_KERNELS
         if (blockIdx.x == 0 && i == 0 && c == 0)
@@ -458,7 +439,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
         double2 z[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) z[k] = img[k * THREADS + t];
-        inverse_step2(z, fw, fv);
+        inverse_step2(z, a.tables[T_W + t], a.tables[T_V + t]);
 #ifdef W16_DEBUG_KERNELS
         if (blockIdx.x == 0 && i == 0 && c == 0)
           for (int q = 0; q < 16; q++) dump_back[512 * q + t] = z[q];

@@ -5,8 +5,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmcfam_$3
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/a -o pmc -- python3 $ROOT/scripts/family_bench.py $1 $2 1 > $OUT/a.log 2>&1 || { echo pass a failed; tail -5 $OUT/a.log; exit 1; }
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT -d $OUT/b -o pmc -- python3 $ROOT/scripts/family_bench.py $1 $2 1 > $OUT/b.log 2>&1 || { echo pass b failed; tail -5 $OUT/b.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/a -o pmc -- python3 $ROOT/scripts/family_bench.py $1 $2 1 ${CAMD_VARIANT:-0} > $OUT/a.log 2>&1 || { echo pass a failed; tail -5 $OUT/a.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT -d $OUT/b -o pmc -- python3 $ROOT/scripts/family_bench.py $1 $2 1 ${CAMD_VARIANT:-0} > $OUT/b.log 2>&1 || { echo pass b failed; tail -5 $OUT/b.log; exit 1; }
 find $OUT -type f \( -name "*.db" -o -name "*.json" \) -delete
 python3 - $OUT <<'PY'
 import csv,glob,sys,collections
