@@ -977,10 +977,11 @@ bool wave_supported(const camd_params& p) {
 }
 
 // every set with an instance gets it by default; the bit-exact kernels stay selectable
+// (CAMD_WAVE_16K=0 keeps the register-blocked kernel as the default of the N = 16384 sets)
 bool wave_default(const camd_params& p) {
   static const bool big = []() {
     const char* e = getenv("CAMD_WAVE_16K");
-    return e ? atoi(e) != 0 : false;
+    return e ? atoi(e) != 0 : true;
   }();
   if (wave16k_supported(p)) return big;
   return wave_supported(p);

@@ -45,8 +45,11 @@ constexpr int T_B = T_A + 9 * 64;      // [pair 8][lo]:   input q carries e^{-2 
 constexpr int T_C = T_B + 8 * 8;       // [pair 9][lane]: inverse, third pass: input b carries the conjugate of e^{-2 pi i lane b/512}
 constexpr int T_LDS = T_C + 9 * 64;    // entries staged in LDS
 constexpr int T_W = T_LDS;             // [t]: e^{i pi t/16384}
-constexpr int T_V = T_W + THREADS;     // [t]: e^{-i pi t/4096}
-constexpr int T_TOTAL = T_V + THREADS;
+constexpr int T_V = T_W + THREADS;     // [t]: e^{-i pi t/4096} = v
+constexpr int T_V2 = T_V + THREADS;    // [t]: v^2
+constexpr int T_V4 = T_V2 + THREADS;   // [t]: v^4
+constexpr int T_V8 = T_V4 + THREADS;   // [t]: v^8
+constexpr int T_TOTAL = T_V8 + THREADS;
 
 constexpr size_t IMAGE_BYTES = (size_t)PTS * THREADS * sizeof(double2);   // 128 KB
 constexpr size_t LDS_BYTES = T_LDS * sizeof(double2) + IMAGE_BYTES;
@@ -210,41 +213,48 @@ __device__ __forceinline__ void fft512_plain_inverse(double2 (&x)[8], int lane, 
 
 // The factors of the sixteen outputs of a thread's radix-16 step are f[k1] = w v^k1 with
 // w = e^{i pi t/16384} (the thread's share of the twist) and v = e^{-i pi t/4096} (the twiddle of the
-// four-step transform). They are formed four at a time, f[j + 4m] = (w v^j) (v^4)^m, so that only
-// five of them are alive at once and no power is more than six products deep.
+// four-step transform). They are formed as f[j + 4m] = (w v^j) (v^4m) from the tabulated w, v, v^2,
+// v^4 and v^8: no factor is more than three products away from correctly rounded values, and the
+// transform's rounding error stays next to that of a transform with fully tabulated twiddles.
+struct StepFactors {
+  double2 w, v, v2, v4, v8;
+};
+__device__ __forceinline__ StepFactors load_step_factors(const double2* tables, int t) {
+  return {tables[T_W + t], tables[T_V + t], tables[T_V2 + t], tables[T_V4 + t], tables[T_V8 + t]};
+}
 template <bool CONJ>
-__device__ __forceinline__ void apply_step_factors(double2 (&z)[16], double2 w, double2 v) {
-  const double2 v2 = cmul(v, v), v4 = cmul(v2, v2);
+__device__ __forceinline__ void apply_step_factors(double2 (&z)[16], const StepFactors& f) {
   double2 b[4];
-  b[0] = w; b[1] = cmul(w, v); b[2] = cmul(w, v2); b[3] = cmul(b[1], v2);
+  b[0] = f.w; b[1] = cmul(f.w, f.v); b[2] = cmul(f.w, f.v2); b[3] = cmul(b[1], f.v2);
+  const double2 c[4] = {make_double2(1.0, 0.0), f.v4, f.v8, cmul(f.v4, f.v8)};
 #pragma unroll
   for (int m = 0; m < 4; m++) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      z[j + 4 * m] = CONJ ? cmul_conj(z[j + 4 * m], b[j]) : cmul(z[j + 4 * m], b[j]);
-      if (m < 3) b[j] = cmul(b[j], v4);
+      const double2 g = m == 0 ? b[j] : cmul(b[j], c[m]);
+      z[j + 4 * m] = CONJ ? cmul_conj(z[j + 4 * m], g) : cmul(z[j + 4 * m], g);
     }
   }
 }
 
 // First half of the forward transform: z[a] = point 512 a + t (untwisted) in; out: the sixteen
 // values Y[k1] that go to row k1 of the transposition image.
-__device__ __forceinline__ void forward_step1(double2 (&z)[16], double2 w, double2 v) {
+__device__ __forceinline__ void forward_step1(double2 (&z)[16], const StepFactors& f) {
 #ifdef W16_DEBUG_NO_STEP
   return;
 #endif
 #pragma unroll
   for (int a = 1; a < 16; a++) z[a] = cmul(z[a], twist16(a));
   dft16<false>(z);
-  apply_step_factors<false>(z, w, v);
+  apply_step_factors<false>(z, f);
 }
 // Last half of the inverse transform: the sixteen values of image column t in, z[a] = 8192 *
 // (coefficient 512 a + t, coefficient 512 a + t + 8192) out (the key carries the 1/8192).
-__device__ __forceinline__ void inverse_step2(double2 (&z)[16], double2 w, double2 v) {
+__device__ __forceinline__ void inverse_step2(double2 (&z)[16], const StepFactors& f) {
 #ifdef W16_DEBUG_NO_STEP
   return;
 #endif
-  apply_step_factors<true>(z, w, v);
+  apply_step_factors<true>(z, f);
   dft16<true>(z);
 #pragma unroll
   for (int a = 1; a < 16; a++) z[a] = cmul_conj(z[a], twist16(a));
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(THREADS) void bsk_fourier_kernel(const T* __restric
     const int j = 512 * a + t;
     z[a] = make_double2(signed_to_double((S)poly[j]) * scale, signed_to_double((S)poly[j + M]) * scale);
   }
-  forward_step1(z, tables[T_W + t], tables[T_V + t]);
+  forward_step1(z, load_step_factors(tables, t));
 #pragma unroll
   for (int k = 0; k < 16; k++) img[k * THREADS + t] = z[k];
   __syncthreads();
@@ -290,7 +300,8 @@ __global__ __launch_bounds__(THREADS) void bsk_fourier_kernel(const T* __restric
 __device__ __forceinline__ uint32_t slab_index(uint32_t j) { return ((j & (M - 1)) << 1) | (j >> LOGM); }
 
 #ifdef W16_DEBUG_KERNELS
-__device__ double2 dump_digits[M], dump_sums[M], dump_back[M];
+__device__ double2 dump_digits[4 * M], dump_sums[M], dump_back[M];
+__device__ int dump_iteration = 0, dump_column = 0;
 #endif
 
 template <typename T, int L, int BL>
@@ -363,10 +374,15 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             uint32_t r0 = hi_half ? pr.y : pr.x, r1 = hi_half ? pr.x : pr.y;   // coefficients s0 mod N and (s0 + M) mod N
             const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)s0, LOGN, 1);
             const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(s0 + M), LOGN, 1);
-            constexpr uint32_t HALF = 1u << (32 - BL * L - 1);
-            // ((rot ^ m) - own) rounded to the top BL L bits, as a signed value
-            int32_t v0 = (int32_t)(((r0 ^ m0) + HALF) - own.x) >> (32 - BL * L);
-            int32_t v1 = (int32_t)(((r1 ^ m1) + HALF) - own.y) >> (32 - BL * L);
+            // (+-rot - own) rounded to the top BL L bits, as a signed value. The difference is known to 2^-32
+            // only, so a tie is one case in 2^(32 - BL L), not one in 2^32 as with 64-bit words: ties go to
+            // the even neighbour (and the negation is exact) so that the rounding has no mean, which a
+            // binary key would add up coherently over the N/2 coefficients it selects.
+            constexpr int DROP = 32 - BL * L;
+            constexpr uint32_t BELOW_HALF = (1u << (DROP - 1)) - 1u;
+            const uint32_t u0 = ((r0 ^ m0) - m0) - own.x, u1 = ((r1 ^ m1) - m1) - own.y;
+            int32_t v0 = (int32_t)(u0 + BELOW_HALF + __builtin_amdgcn_ubfe(u0, DROP, 1)) >> DROP;
+            int32_t v1 = (int32_t)(u1 + BELOW_HALF + __builtin_amdgcn_ubfe(u1, DROP, 1)) >> DROP;
 #pragma unroll
             for (int m = L; m > l; m--) {                                        // strip the digits below level l
               v0 = (v0 - (int32_t)__builtin_amdgcn_sbfe(v0, 0, BL)) >> BL;
@@ -380,11 +396,11 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four points' loads in flight at a time: registers are short
           }
 #ifdef W16_DEBUG_KERNELS
-          if (blockIdx.x == 0 && i == 0 && r == 0 && l == 1)
-            for (int q = 0; q < 16; q++) dump_digits[512 * q + t] = z[q];
+          if (blockIdx.x == 0 && (int)i == dump_iteration)
+            for (int q = 0; q < 16; q++) dump_digits[(r * 2 + (l - 1)) * M + 512 * q + t] = z[q];
 #endif
           __builtin_amdgcn_sched_barrier(0);
-          forward_step1(z, a.tables[T_W + t], a.tables[T_V + t]);
+          forward_step1(z, load_step_factors(a.tables, t));
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();               // everyone is done with the image's previous content
 #pragma unroll
@@ -425,7 +441,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
         const int lane = t & 63, wave = t >> 6;
         __syncthreads();                 // everyone is done with the image's previous content
 #ifdef W16_DEBUG_KERNELS
-        if (blockIdx.x == 0 && i == 0 && c == 0)
+        if (blockIdx.x == 0 && (int)i == dump_iteration && c == dump_column)
           for (int e = 0; e < 2; e++)
             for (int g = 0; g < 8; g++) dump_sums[wave * 1024 + (e * 8 + g) * 64 + lane] = S[c][e][g];
 #endif
@@ -439,9 +455,9 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
         double2 z[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) z[k] = img[k * THREADS + t];
-        inverse_step2(z, a.tables[T_W + t], a.tables[T_V + t]);
+        inverse_step2(z, load_step_factors(a.tables, t));
 #ifdef W16_DEBUG_KERNELS
-        if (blockIdx.x == 0 && i == 0 && c == 0)
+        if (blockIdx.x == 0 && (int)i == dump_iteration && c == dump_column)
           for (int q = 0; q < 16; q++) dump_back[512 * q + t] = z[q];
 #endif
         uint32_t* pc = acc + c * N;
@@ -477,7 +493,6 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
   for (int i = threadIdx.x; i < T_LDS; i += THREADS) tab[i] = tables[i];
   __syncthreads();
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const double2 fw = tables[T_W + t], fv = tables[T_V + t];
   if (mode == 1 || mode == 2) {
     double2 x[8];
 #pragma unroll
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
     double2 z[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) z[a] = in[512 * a + t];
-    forward_step1(z, fw, fv);
+    forward_step1(z, load_step_factors(tables, t));
 #pragma unroll
     for (int k = 0; k < 16; k++) img[k * THREADS + t] = z[k];
     __syncthreads();
@@ -516,7 +531,7 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
     double2 z[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) z[k] = img[k * THREADS + t];
-    inverse_step2(z, fw, fv);
+    inverse_step2(z, load_step_factors(tables, t));
 #pragma unroll
     for (int a = 0; a < 16; a++) out[512 * a + t] = z[a];
   }
@@ -572,9 +587,13 @@ void wave16k_fill_tables(double2* t) {
     fold(t + w16::T_B + lo, 8, th, false);
   }
   for (int i = 0; i < w16::THREADS; i++) {
-    const double aw = M_PI * (double)i / 16384.0, av = -M_PI * (double)i / 4096.0;
+    const double aw = M_PI * (double)i / 16384.0;
     t[w16::T_W + i] = make_double2(std::cos(aw), std::sin(aw));
-    t[w16::T_V + i] = make_double2(std::cos(av), std::sin(av));
+    const int power_tables[4] = {w16::T_V, w16::T_V2, w16::T_V4, w16::T_V8};
+    for (int s = 0; s < 4; s++) {
+      const double av = -M_PI * (double)(i << s) / 4096.0;
+      t[power_tables[s] + i] = make_double2(std::cos(av), std::sin(av));
+    }
   }
 }
 
@@ -617,7 +636,17 @@ template int wave16k_launch_pbs<uint32_t>(const PbsLaunch<uint32_t>&, hipStream_
 extern "C" int camd_debug_w16_dump(int which, double* out_host) {
   const size_t bytes = (size_t)w16::M * sizeof(double2);
   CAMD_HIP(hipDeviceSynchronize());
-  if (which == 0) CAMD_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w16::dump_digits), bytes));
+  if (which >= 100) {
+    const int col = which - 100;
+    CAMD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(w16::dump_column), &col, sizeof(int)));
+    return CAMD_OK;
+  }
+  if (which >= 10) {
+    const int it = which - 10;
+    CAMD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(w16::dump_iteration), &it, sizeof(int)));
+    return CAMD_OK;
+  }
+  if (which == 0) CAMD_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w16::dump_digits), 4 * bytes));
   if (which == 1) CAMD_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w16::dump_sums), bytes));
   if (which == 2) CAMD_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w16::dump_back), bytes));
   return CAMD_OK;

@@ -341,28 +341,43 @@ def test_wave_kernel_small_shortint_sets(gpu_ctx, pname):
     dk.close()
 
 
-@pytest.mark.parametrize("pname,count", [("PARAM_MESSAGE_4_CARRY_4", 16), ("PARAM_MESSAGE_1_CARRY_7", 8)])
-def test_largest_polynomial_full_size_bit_exact(gpu_ctx, pname, count):
-    """The largest-polynomial class (N = 16384, two and three decomposition levels) at its FULL
-    LWE dimension with real keys: keyswitch + bootstrap through the C ABI must give the oracle's
-    ciphertexts word for word (the register-blocked kernel's contract) and every ciphertext must
-    decrypt to f(m) (the property of concrete-shortint/src/server_key/tests.rs:252-277).
-    Parameter sets: concrete-shortint/src/parameters/mod.rs:719-736 and :665-682.
-    The 1 GB bootstrap key is generated by the library's multithreaded host key generation, which
-    is the same algorithm as the oracle's single-threaded one (tests/test_host_cpu.py compares them)."""
+@pytest.fixture(scope="module")
+def full_size_keys():
+    """Real keys of the N = 16384 sets at their full LWE dimension, generated once per set for the
+    tests below (1 GB of bootstrap key each, from the library's multithreaded host key generation:
+    the same algorithm as the oracle's single-threaded one, which tests/test_host_cpu.py compares)."""
     from concrete_amd import client as CL
 
-    p = P.SHORTINT_BY_NAME[pname]
+    made = {}
+
+    def get(pname):
+        if pname not in made:
+            made.clear()                        # one set at a time: the keys are large
+            p = P.SHORTINT_BY_NAME[pname]
+            rng = CL.Rng(0xBEEF)
+            small = CL.gen_binary_key(rng, 64, p.lwe_dimension)
+            glwe = CL.gen_binary_key(rng, 64, p.glwe_dimension * p.polynomial_size)
+            bsk = CL.gen_bootstrap_key(rng, p, 64, small, glwe, threads=16)
+            ksk = CL.gen_keyswitch_key(rng, p, 64, glwe, small)
+            made[pname] = (p, small, glwe, bsk, ksk)
+        return made[pname]
+
+    yield get
+    made.clear()
+
+
+@pytest.mark.parametrize("pname,count", [("PARAM_MESSAGE_4_CARRY_4", 16), ("PARAM_MESSAGE_1_CARRY_7", 8)])
+def test_largest_polynomial_full_size_bit_exact(gpu_ctx, full_size_keys, pname, count):
+    """The largest-polynomial class (N = 16384, two and three decomposition levels) at its FULL
+    LWE dimension with real keys: keyswitch + bootstrap through the C ABI with the register-blocked
+    kernel must give the oracle's ciphertexts word for word (that kernel's contract) and every
+    ciphertext must decrypt to f(m) (the property of concrete-shortint/src/server_key/tests.rs:252-277).
+    Parameter sets: concrete-shortint/src/parameters/mod.rs:719-736 and :665-682."""
+    p, small, glwe, bsk, ksk = full_size_keys(pname)
     o = O.Oracle(p, 64)
-    rng = CL.Rng(0xBEEF)
-    small = CL.gen_binary_key(rng, 64, p.lwe_dimension)
-    glwe = CL.gen_binary_key(rng, 64, p.glwe_dimension * p.polynomial_size)
-    bsk = CL.gen_bootstrap_key(rng, p, 64, small, glwe, threads=16)
-    ksk = CL.gen_keyswitch_key(rng, p, 64, glwe, small)
-    dk = DeviceServerKey.from_standard_keys(gpu_ctx, p, bsk, ksk, variant=CAMD_PBS_AUTO)
+    dk = DeviceServerKey.from_standard_keys(gpu_ctx, p, bsk, ksk, variant=CAMD_PBS_BLOCK)
     assert dk.variant == CAMD_PBS_BLOCK
     fbsk = o.bsk_to_fourier(bsk)
-    del bsk
     msg, sup = p.message_modulus, p.message_modulus * p.carry_modulus
     fs = [lambda x: x % msg, lambda x: x // msg]
     luts = [o.generate_accumulator(f) for f in fs]
@@ -381,6 +396,54 @@ def test_largest_polynomial_full_size_bit_exact(gpu_ctx, pname, count):
     for i, m in enumerate(msgs):
         assert O.shortint_decode(p, o.lwe_phase(glwe, got[i])) == fs[i % 2](m), (i, m)
     dk.close()
+
+
+def test_largest_polynomial_full_size_throughput_kernel(gpu_ctx, full_size_keys):
+    """PARAM_MESSAGE_4_CARRY_4 at its full LWE dimension through the kernel CAMD_PBS_AUTO selects for it
+    (pbs_wave16k.hip): 2048 fresh ciphertexts over the whole 8-bit message space must decrypt to
+    f(m), and the variance of the output phase error must stay within the predicted figure and
+    next to the reference algorithm's on the same inputs. The reference values come from the
+    register-blocked kernel, which the test above pins to the oracle word for word at this size
+    (the oracle itself takes seconds per bootstrap here). The prediction is the gadget noise, the
+    f64 transforms' rounding and this kernel's own term: it keeps 32 bits per accumulator
+    coefficient, so every CMUX rounds its increment at 2^-32 of the torus (variance 2^-64 / 12
+    per coefficient, times 1 + kN/2 through the binary key at decryption). At this size the
+    transforms' rounding is most of the output noise, and this kernel's four-step transform
+    rounds a little less than the reference's (measured ratio of the variances: 0.75), hence the
+    lower bar of the ratio."""
+    from concrete_amd import client as CL
+    from concrete_amd.backend import CAMD_PBS_AUTO
+    from test_gpu_parity import check_noise_variance, fft_variance, gadget_variance
+
+    pname = "PARAM_MESSAGE_4_CARRY_4"
+    p, small, glwe, bsk, ksk = full_size_keys(pname)
+    o = O.Oracle(p, 64)
+    dk = DeviceServerKey.from_standard_keys(gpu_ctx, p, bsk, ksk, variant=CAMD_PBS_AUTO)
+    assert dk.variant == CAMD_PBS_WAVE
+    ref = DeviceServerKey.from_standard_keys(gpu_ctx, p, bsk, ksk, variant=CAMD_PBS_BLOCK)
+    msg, sup = p.message_modulus, p.message_modulus * p.carry_modulus
+    lut = o.generate_accumulator(lambda x: x % msg)
+    dk.upload_lut(lut)
+    ref.upload_lut(lut)
+    delta = O.shortint_delta(p)
+    count = 2048
+    msgs = np.arange(count) % sup
+    cts = CL.lwe_encrypt(CL.Rng(77), 64, glwe, [int(m) * delta for m in msgs], p.lwe_modular_std_dev)
+    got = dk.ks_pbs(cts)
+    want = ref.ks_pbs(cts)
+    n, k, N = p.lwe_dimension, p.glwe_dimension, p.polynomial_size
+    gadget = gadget_variance(p)
+    accumulator_rounding = n * (1.0 + k * N / 2.0) * 2.0 ** -64 / 12.0
+    bound = gadget + fft_variance(p, o) + accumulator_rounding
+    nearest = lambda ph: ((ph + np.uint64(delta // 2)) // np.uint64(delta)) * np.uint64(delta)
+    near_g, near_w = check_noise_variance(64, count, count, bound, gadget, got, want, glwe, nearest, pname,
+                                           ratio_bar=(0.55, 1.15))
+    dec_g, dec_w = (near_g // np.uint64(delta)) % np.uint64(2 * sup), (near_w // np.uint64(delta)) % np.uint64(2 * sup)
+    assert np.array_equal(dec_g, dec_w)
+    assert np.array_equal(dec_g, (msgs % msg).astype(np.uint64))
+    assert np.all(got & np.uint64(0xFFFFFFFF) == 0)       # the 32-bit accumulator: low dwords are zero
+    dk.close()
+    ref.close()
 
 
 @pytest.mark.parametrize("n", [1, 7])

@@ -160,10 +160,10 @@ def fft_variance(p, o):
     return n * (k + 1) * L * (1.0 + k * N / 2.0) * np.concatenate(errs).var()
 
 
-def check_noise_variance(bits, count, sub, bound, gadget, got, want, key, nearest_of, label):
+def check_noise_variance(bits, count, sub, bound, gadget, got, want, key, nearest_of, label, ratio_bar=(0.75, 1.15)):
     """The three assertions of the noise acceptance bar, shared by every wave instance:
     gadget < variance < 1.2 x predicted for the GPU (all `count` outputs) and for the oracle (the
-    first `sub`), the two variances within (0.75, 1.15) of each other on the same inputs, and no
+    first `sub`), the two variances within `ratio_bar` of each other on the same inputs, and no
     bias. `nearest_of(phase)` returns the plaintext the phase decodes to (same dtype), `key` the
     secret key the outputs are under. Returns the decoded plaintexts of both."""
     from concrete_amd import client as CL
@@ -183,7 +183,7 @@ def check_noise_variance(bits, count, sub, bound, gadget, got, want, key, neares
     assert gadget < err_g.var() < 1.2 * bound, (label, err_g.var(), bound)
     assert gadget < err_w.var() < 1.2 * bound, (label, err_w.var(), bound)
     ratio = err_g[:sub].var() / err_w.var()
-    assert 0.75 < ratio < 1.15, (label, ratio)
+    assert ratio_bar[0] < ratio < ratio_bar[1], (label, ratio)
     assert abs(err_g.mean()) < 4 * np.sqrt(bound / count), (label, err_g.mean())   # no bias from the fast rounding
     return dec_g, dec_w
 
