@@ -176,8 +176,26 @@ __device__ __forceinline__ void transpose_2_0(double2 (&x)[8], int lane) {
   W16_STAGE_FENCE();
 }
 
+// The same exchange through 8 KB of LDS that belong to the wave alone (the image row of the
+// sub-transform it is working on): sixteen 16-byte accesses and as many address XORs instead of 160
+// lane-permute and select instructions; the vector ALU is what this kernel runs out of, the LDS is
+// idle. Lane (hi, l) stores register r in row 8 hi + (l ^ f), slot r ^ l, with f = bit 1 of hi:
+// the slot XOR keeps the eight lanes of a store group on different banks, f keeps the two lanes of a
+// 16-lane load group that share l on different halves of the 64 banks. No barrier: the LDS executes
+// one wave's accesses in order.
+__device__ __forceinline__ void transpose_2_0_lds(double2 (&x)[8], int lane, double2* row) {
+  const uint32_t hi = (uint32_t)lane >> 3, l = (uint32_t)lane & 7, f = (hi >> 1) & 1;
+  char* base = (char*)row;
+  const uint32_t wbase = (hi * 8 + (l ^ f)) * 128 + l * 16;     // + (r * 16 XORed in)
+  const uint32_t rbase = (hi * 8 + f) * 128 + l * 16;           // + (q * 128 and q * 16 XORed in)
+#pragma unroll
+  for (int r = 0; r < 8; r++) *(double2*)(base + (wbase ^ (uint32_t)(r * 16))) = x[r];
+#pragma unroll
+  for (int q = 0; q < 8; q++) x[q] = *(const double2*)(base + (rbase ^ (uint32_t)(q * 144)));
+}
+
 // 512-point transform on one wave: x[a] = point 64 a + lane in, x[g] = X[64 g + 8 (lane & 7) + (lane >> 3)] out
-__device__ __forceinline__ void fft512_plain_forward(double2 (&x)[8], int lane, const double2* tab) {
+__device__ __forceinline__ void fft512_plain_forward_head(double2 (&x)[8], int lane, const double2* tab, double2* row) {
 #ifdef W16_DEBUG_NO_FFT512
   return;
 #endif
@@ -187,19 +205,27 @@ __device__ __forceinline__ void fft512_plain_forward(double2 (&x)[8], int lane, 
     const Tw8 k = load_tw8<true>(tab + T_A + lane, 64);
     dft8_tw<false, true>(x, k);
   }
-  transpose_2_0(x, lane);
-  {
-    const Tw8 k = load_tw8<false>(tab + T_B + (lane & 7), 8);
-    dft8_tw<false, false>(x, k);
-  }
+  transpose_2_0_lds(x, lane, row);
+}
+// the last of the three passes, apart so that a caller can start loads in front of it
+__device__ __forceinline__ void fft512_plain_forward_tail(double2 (&x)[8], int lane, const double2* tab) {
+#ifdef W16_DEBUG_NO_FFT512
+  return;
+#endif
+  const Tw8 k = load_tw8<false>(tab + T_B + (lane & 7), 8);
+  dft8_tw<false, false>(x, k);
+}
+__device__ __forceinline__ void fft512_plain_forward(double2 (&x)[8], int lane, const double2* tab, double2* row) {
+  fft512_plain_forward_head(x, lane, tab, row);
+  fft512_plain_forward_tail(x, lane, tab);
 }
 // unnormalised inverse: spectrum in the order above in, x[a] = 512 * point (64 a + lane) out
-__device__ __forceinline__ void fft512_plain_inverse(double2 (&x)[8], int lane, const double2* tab) {
+__device__ __forceinline__ void fft512_plain_inverse(double2 (&x)[8], int lane, const double2* tab, double2* row) {
 #ifdef W16_DEBUG_NO_FFT512
   return;
 #endif
   dft8<true>(x);
-  transpose_2_0(x, lane);
+  transpose_2_0_lds(x, lane, row);
   {
     const Tw8 k = load_tw8<false>(tab + T_B + (lane & 7), 8);
     dft8_tw<true, false>(x, k);
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(THREADS) void bsk_fourier_kernel(const T* __restric
     double2 x[8];
 #pragma unroll
     for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
-    fft512_plain_forward(x, lane, tab);
+    fft512_plain_forward(x, lane, tab, img + (2 * wave + e) * THREADS);
 #pragma unroll
     for (int g = 0; g < 8; g++) dst[(e * 8 + g) * 64 + lane] = make_double2(x[g].x * (1.0 / M), x[g].y * (1.0 / M));
   }
@@ -367,9 +393,13 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
           for (int q = 0; q < 16; q++) {
             const uint32_t j0 = 512 * q + t;                                   // and j0 + M
-            const uint2 own = *(const uint2*)(p + 2 * j0);
             const uint32_t s0 = (j0 - a_hat) & (2 * N - 1);                     // rotated index of j0; that of j0 + M is s0 + M
+#ifdef W16_TIMING_NO_GATHER                                                     // timing experiments only: wrong results
+            const uint2 own = make_uint2(j0 * 2654435761u, s0 * 40503u), pr = make_uint2(s0 * 2246822519u, j0 * 3266489917u);
+#else
+            const uint2 own = *(const uint2*)(p + 2 * j0);
             const uint2 pr = *(const uint2*)(p + 2 * (s0 & (M - 1)));
+#endif
             const bool hi_half = (s0 & M) != 0;
             uint32_t r0 = hi_half ? pr.y : pr.x, r1 = hi_half ? pr.x : pr.y;   // coefficients s0 mod N and (s0 + M) mod N
             const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)s0, LOGN, 1);
@@ -413,22 +443,33 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             double2 x[8];
 #pragma unroll
             for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
-            fft512_plain_forward(x, lane, tab);
+            fft512_plain_forward_head(x, lane, tab, img + (2 * wave + e) * THREADS);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < R; c++) {      // one column at a time: eight key values in flight, not sixteen
-              double2 kq[8];
+            // the key values of the first column are requested in front of the last pass, those of the second
+            // one behind it: their way from the L2 overlaps with that pass and with the first column's products
+            double2 kq[R][8];
+            auto request = [&](int c) {
 #pragma unroll
               for (int g = 0; g < 8; g++) {
                 const auto w = __builtin_amdgcn_raw_buffer_load_b128(
                     key_rsrc, (int)(key_lane + (g & 3) * 1024),
                     (int)(key_base + (uint32_t)c * (uint32_t)(M * sizeof(double2)) + e * 8192 + (g >> 2) * 4096), 0);
-                kq[g] = as_double2(__builtin_bit_cast(v4u, w));
+                kq[c][g] = as_double2(__builtin_bit_cast(v4u, w));
+#ifdef W16_TIMING_NO_KEY
+                kq[c][g] = make_double2(1e-3 * (double)(g + 1), 2e-3);
+#endif
               }
+            };
+            request(0);
+            __builtin_amdgcn_sched_barrier(0);
+            fft512_plain_forward_tail(x, lane, tab);
+            __builtin_amdgcn_sched_barrier(0);
+            request(1);
 #pragma unroll
-              for (int g = 0; g < 8; g++) S[c][e][g] = cfma(kq[g], x[g], S[c][e][g]);
-              __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int c = 0; c < R; c++)
+#pragma unroll
+              for (int g = 0; g < 8; g++) S[c][e][g] = cfma(kq[c][g], x[g], S[c][e][g]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -447,7 +488,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
 #endif
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-          fft512_plain_inverse(S[c][e], lane, tab);
+          fft512_plain_inverse(S[c][e], lane, tab, img + (2 * wave + e) * THREADS);
 #pragma unroll
           for (int g = 0; g < 8; g++) img[(2 * wave + e) * THREADS + 64 * g + lane] = S[c][e][g];
         }
@@ -464,7 +505,11 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
           const uint32_t j0 = 512 * q + t;
+#ifdef W16_TIMING_NO_UPDATE_LOAD
+          uint2 old = make_uint2(j0, j0 * 7u);
+#else
           uint2 old = *(const uint2*)(pc + 2 * j0);
+#endif
           old.x = torus_accumulate(old.x, z[q].x);
           old.y = torus_accumulate(old.y, z[q].y);
           *(uint2*)(pc + 2 * j0) = old;
@@ -497,7 +542,7 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
     double2 x[8];
 #pragma unroll
     for (int g = 0; g < 8; g++) x[g] = in[wave * 512 + 64 * g + lane];
-    if (mode == 1) fft512_plain_forward(x, lane, tab); else fft512_plain_inverse(x, lane, tab);
+    if (mode == 1) fft512_plain_forward(x, lane, tab, img + wave * THREADS); else fft512_plain_inverse(x, lane, tab, img + wave * THREADS);
 #pragma unroll
     for (int g = 0; g < 8; g++) out[wave * 512 + 64 * g + lane] = x[g];
   } else if (mode == 3) {
@@ -513,7 +558,7 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
       double2 x[8];
 #pragma unroll
       for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
-      fft512_plain_forward(x, lane, tab);
+      fft512_plain_forward(x, lane, tab, img + (2 * wave + e) * THREADS);
 #pragma unroll
       for (int g = 0; g < 8; g++) out[wave * 1024 + (e * 8 + g) * 64 + lane] = x[g];
     }
@@ -523,7 +568,7 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
       double2 x[8];
 #pragma unroll
       for (int g = 0; g < 8; g++) x[g] = in[wave * 1024 + (e * 8 + g) * 64 + lane];
-      fft512_plain_inverse(x, lane, tab);
+      fft512_plain_inverse(x, lane, tab, img + (2 * wave + e) * THREADS);
 #pragma unroll
       for (int g = 0; g < 8; g++) img[(2 * wave + e) * THREADS + 64 * g + lane] = x[g];
     }
