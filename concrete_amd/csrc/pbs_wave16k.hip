@@ -195,7 +195,7 @@ __device__ __forceinline__ void transpose_2_0_lds(double2 (&x)[8], int lane, dou
 }
 
 // 512-point transform on one wave: x[a] = point 64 a + lane in, x[g] = X[64 g + 8 (lane & 7) + (lane >> 3)] out
-__device__ __forceinline__ void fft512_plain_forward_head(double2 (&x)[8], int lane, const double2* tab, double2* row) {
+__device__ __forceinline__ void fft512_plain_forward_head(double2 (&x)[8], int lane, const double2* tab) {
 #ifdef W16_DEBUG_NO_FFT512
   return;
 #endif
@@ -205,19 +205,19 @@ __device__ __forceinline__ void fft512_plain_forward_head(double2 (&x)[8], int l
     const Tw8 k = load_tw8<true>(tab + T_A + lane, 64);
     dft8_tw<false, true>(x, k);
   }
-  transpose_2_0_lds(x, lane, row);
 }
 // the last of the three passes, apart so that a caller can start loads in front of it
-__device__ __forceinline__ void fft512_plain_forward_tail(double2 (&x)[8], int lane, const double2* tab) {
+__device__ __forceinline__ void fft512_plain_forward_tail(double2 (&x)[8], int lane, const double2* tab, double2* row) {
 #ifdef W16_DEBUG_NO_FFT512
   return;
 #endif
+  transpose_2_0_lds(x, lane, row);
   const Tw8 k = load_tw8<false>(tab + T_B + (lane & 7), 8);
   dft8_tw<false, false>(x, k);
 }
 __device__ __forceinline__ void fft512_plain_forward(double2 (&x)[8], int lane, const double2* tab, double2* row) {
-  fft512_plain_forward_head(x, lane, tab, row);
-  fft512_plain_forward_tail(x, lane, tab);
+  fft512_plain_forward_head(x, lane, tab);
+  fft512_plain_forward_tail(x, lane, tab, row);
 }
 // unnormalised inverse: spectrum in the order above in, x[a] = 512 * point (64 a + lane) out
 __device__ __forceinline__ void fft512_plain_inverse(double2 (&x)[8], int lane, const double2* tab, double2* row) {
@@ -443,9 +443,9 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             double2 x[8];
 #pragma unroll
             for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
-            fft512_plain_forward_head(x, lane, tab, img + (2 * wave + e) * THREADS);
+            fft512_plain_forward_head(x, lane, tab);
             __builtin_amdgcn_sched_barrier(0);
-            // the key values of the first column are requested in front of the last pass, those of the second
+            // the key values of the first column are requested in front of the last exchange and pass, those of the second
             // one behind it: their way from the L2 overlaps with that pass and with the first column's products
             double2 kq[R][8];
             auto request = [&](int c) {
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             };
             request(0);
             __builtin_amdgcn_sched_barrier(0);
-            fft512_plain_forward_tail(x, lane, tab);
+            fft512_plain_forward_tail(x, lane, tab, img + (2 * wave + e) * THREADS);
             __builtin_amdgcn_sched_barrier(0);
             request(1);
 #pragma unroll
