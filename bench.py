@@ -44,8 +44,15 @@ from concrete_amd.shortint import ClientKey  # noqa: E402
 # image lists no FP64 row, so it is not a measured peak.
 FP64_PEAK_TFLOPS = 78.6
 SEED = 0xC0FFEE
-CPU_SAMPLE = 4096                # ciphertexts timed on the host cores (about 10 s on 16 threads)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r3", "pmc_per_dispatch_final.json")
+PROFILES = os.path.join(ROOT, "profiles", "r3")
+# shortint workloads: parameter set, default batch per GPU, ciphertexts timed on the host cores
+# (10-30 s on 16 threads), the bootstrap kernel CAMD_PBS_AUTO launches for it and the committed
+# counter summary of this same command, failure probability of the parameter set per bootstrap
+SHORTINT_WORKLOADS = {
+    "2_2": ("PARAM_MESSAGE_2_CARRY_2", 1 << 14, 4096, "wave8_pbs_kernel", "pmc_per_dispatch_final.json", 2.0 ** -13.9),
+    "4_4": ("PARAM_MESSAGE_4_CARRY_4", 512, 256, "w16::pbs_kernel", "pmc_per_dispatch_4_4_final.json", None),
+    "3_3": ("PARAM_MESSAGE_3_CARRY_3", 4096, 128, None, None, None),
+}
 CSRC = os.path.join(ROOT, "concrete_amd", "csrc")
 
 
@@ -59,15 +66,16 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel: str):
+def measured_traffic(kernel: str, summary: str):
     """(bytes per launch, provenance) of `kernel` from the committed rocprofv3 counter passes of
     this same command (FETCH_SIZE and WRITE_SIZE cannot be read from inside the process). The
     figure is only reported when the summary was taken from the kernel sources as they are now."""
+    path = os.path.join(PROFILES, summary)
     try:
-        with open(PMC_SUMMARY) as f:
+        with open(path) as f:
             doc = json.load(f)
         e = doc[kernel]
-        prov = {"from_profile": os.path.relpath(PMC_SUMMARY, ROOT), "profile_source_hash": doc.get("source_hash"),
+        prov = {"from_profile": os.path.relpath(path, ROOT), "profile_source_hash": doc.get("source_hash"),
                 "source_hash": kernel_source_hash()}
         if doc.get("source_hash") != prov["source_hash"]:
             return None, dict(prov, stale=True)
@@ -135,8 +143,6 @@ def cpu_baseline(p, bsk, ksk, lut, cts_host, cores: int):
 
 OTHER_WORKLOADS = {
     # name: (parameter set, default batch per GPU, torus bits, order)
-    "4_4": ("PARAM_MESSAGE_4_CARRY_4", 512, 64, "ks_pbs"),
-    "3_3": ("PARAM_MESSAGE_3_CARRY_3", 4096, 64, "ks_pbs"),
     "boolean": ("DEFAULT_PARAMETERS", 1 << 15, 32, "pbs_ks"),
 }
 
@@ -287,7 +293,7 @@ def plumbing(args) -> None:
     census = rk.census()
     if rk.rank == 0:
         emit({
-            "metric": "bootstraps/sec (node), MESSAGE_2_CARRY_2", "value": None, "unit": "bootstraps/s",
+            "metric": f"bootstraps/sec (node), {short_name}", "value": None, "unit": "bootstraps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "none",
             "plumbing_only": True, **census,
@@ -299,8 +305,8 @@ def plumbing(args) -> None:
 
 
 def other_workload(args) -> None:
-    """Further configurations (largest polynomial size, boolean gates): same contract, random key
-    material and random ciphertexts, so there is no decryption check and no CPU baseline."""
+    """The boolean gate bootstrap (PBS then keyswitch): same contract, random key material and
+    random ciphertexts, so there is no decryption check and no CPU baseline."""
     rk = Ranks(args)
     world, rank, dist = rk.world, rk.rank, rk.dist
     pname, default_batch, bits, order = OTHER_WORKLOADS[args.workload]
@@ -455,9 +461,10 @@ def main() -> None:
     ap.add_argument("--luts", type=int, default=1, help="number of distinct look-up tables spread over the batch")
     ap.add_argument("--plumbing", action="store_true",
                     help="rank plumbing only, on the CPU with gloo: no GPU and no kernels (value is null)")
-    ap.add_argument("--workload", default="2_2", choices=sorted(OTHER_WORKLOADS) + ["2_2", "fheuint8"],
-                    help="2_2 (default) is the headline configuration; the others time further configurations of the "
-                         "same path with random key material (timing does not depend on the data)")
+    ap.add_argument("--workload", default="2_2", choices=sorted(OTHER_WORKLOADS) + sorted(SHORTINT_WORKLOADS) + ["fheuint8"],
+                    help="2_2 (default) is the headline configuration; 4_4 and 3_3 run the same measurement (real keys, "
+                         "decryption check, CPU baseline) on further parameter sets; boolean times the gate bootstrap "
+                         "with random key material")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
@@ -472,15 +479,17 @@ def main() -> None:
         return plumbing(args)
     if args.workload == "fheuint8":
         return fheuint8_workload(args)
-    if args.workload != "2_2":
+    if args.workload in OTHER_WORKLOADS:
         return other_workload(args)
 
     rk = Ranks(args)
     world, rank, dist = rk.world, rk.rank, rk.dist
     device = rk.device
 
-    p = P.PARAM_MESSAGE_2_CARRY_2
-    count = args.batch
+    pname, default_batch, cpu_sample, auto_kernel, pmc_summary, failure_rate = SHORTINT_WORKLOADS[args.workload]
+    p = getattr(P, pname)
+    short_name = pname.replace("PARAM_", "")
+    count = args.batch if args.batch != 1 << 14 else default_batch
     ctx = Context(rk.device_index)
     cks = ClientKey(p, seed=SEED)  # secret keys only: cheap and identical on every rank (fixed test seed)
 
@@ -488,7 +497,8 @@ def main() -> None:
     bsk = ksk = None
     t_key = time.perf_counter()
     if rank == 0:
-        bsk = CL.gen_bootstrap_key(cks._rng, p, 64, cks.lwe_secret_key_after_ks, cks.glwe_secret_key)
+        bsk = CL.gen_bootstrap_key(cks._rng, p, 64, cks.lwe_secret_key_after_ks, cks.glwe_secret_key,
+                                   threads=min(16, os.cpu_count() or 1))
         ksk = CL.gen_keyswitch_key(cks._rng, p, 64, cks.lwe_secret_key, cks.lwe_secret_key_after_ks)
         dk = DeviceServerKey.from_standard_keys(ctx, p, bsk, ksk, variant=args.variant)
     key_broadcast_ms = None
@@ -552,12 +562,14 @@ def main() -> None:
         # the counters of the default schedule (two waves per SIMD); another schedule asked for through
         # CAMD_WAVE_SCHEDULE has no committed summary
         default_schedule = os.environ.get("CAMD_WAVE_SCHEDULE", "3") == "3"
-        traffic, provenance = (measured_traffic("wave8_pbs_kernel") if dk.variant == 2 and count == 1 << 14 and default_schedule
+        traffic, provenance = (measured_traffic(auto_kernel, pmc_summary)
+                               if auto_kernel and dk.variant == 2 and count == default_batch and default_schedule
                                else (None, {"from_profile": None}))
+        key_mb = p.lwe_dimension * p.pbs_level * (p.glwe_dimension + 1) ** 2 * (p.polynomial_size // 2) * 16 / 1e6
         measured_peak = ctx.measure_fp64_fma_rate()   # 5 ms probe: what v_fma_f64 sustains on this GPU right now
         ks_macs = p.glwe_dimension * p.polynomial_size * p.ks_level * (p.lwe_dimension + 1)
         line = {
-            "metric": "bootstraps/sec (node), MESSAGE_2_CARRY_2",
+            "metric": f"bootstraps/sec (node), {short_name}",
             "value": value,
             "unit": "bootstraps/s",
             "n_gpus": world,
@@ -573,8 +585,8 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "concrete-shortint PARAM_MESSAGE_2_CARRY_2 keyswitch+PBS, batch 2^14 fresh ciphertexts per GPU, "
-                            "inputs resident in HBM, " + ("one shared look-up table (x % 4)" if args.luts == 1 else
+                "workload": f"concrete-shortint {pname} keyswitch+PBS, batch {count} fresh ciphertexts per GPU, "
+                            "inputs resident in HBM, " + (f"one shared look-up table (x % {p.message_modulus})" if args.luts == 1 else
                                                          f"{args.luts} look-up tables interleaved over the batch"),
                 "batch_per_gpu": count,
                 "global_batch": count * world,
@@ -599,8 +611,11 @@ def main() -> None:
                 "executed_fp64_tflops": (provenance.get("counted_fp64_flop_per_launch") / pbs_s / 1e12
                                          if traffic is not None and provenance.get("counted_fp64_flop_per_launch") and pbs_s > 0 else None),
                 "traffic_unit": "bytes per launch past the L2 (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, "
-                                "from the committed summary; null when the kernel sources changed since); the Fourier "
-                                "key is 56.7 MB and stays in the Infinity Cache, so this is fabric, not HBM, traffic",
+                                f"from the committed summary; null when the kernel sources changed since); the Fourier "
+                                f"key is {key_mb:.1f} MB" + (" and stays in the Infinity Cache, so this is fabric, not HBM, traffic"
+                                                             if key_mb < 200 else
+                                                             "; most of the figure is the per-ciphertext accumulators (32 bits per "
+                                                             "coefficient, 128 KB per ciphertext) leaving and re-entering the L2 once per CMUX"),
                 "kernel": "programmable bootstrap (blind rotation), f64 on the vector ALUs",
                 "flop_per_bootstrap": fpp,
                 "kernel_ms": tm["pbs_ms"],
@@ -617,7 +632,7 @@ def main() -> None:
             # about 2^-13.9 per bootstrap (keyswitch + modulus-switch noise against the half box),
             # i.e. about one ciphertext per 2^14 batch on ANY correct implementation.
             "decrypt_differs_from_cleartext": wrong,
-            "expected_failures_of_parameter_set": count * world * 2.0 ** -13.9,
+            "expected_failures_of_parameter_set": count * world * failure_rate if failure_rate else None,
             "key_setup_s": key_setup_s,
             "key_broadcast_ms": key_broadcast_ms,
         }
@@ -625,7 +640,7 @@ def main() -> None:
             # the same pass through the host-pointer entry point: pageable host buffers in and out,
             # PCIe both ways inside the time. Reported beside `value`, never as `value`.
             host_in = cts.cpu().numpy().view(np.uint64)
-            dk.ks_pbs(host_in[:2048], None if lut_ids is None else lut_ids[:2048].cpu().numpy())  # staging buffers, first touch
+            dk.ks_pbs(host_in[: min(2048, count)], None if lut_ids is None else lut_ids[: min(2048, count)].cpu().numpy())  # staging buffers, first touch
             th = time.perf_counter()
             host_out = dk.ks_pbs(host_in, None if lut_ids is None else lut_ids.cpu().numpy())
             dth = time.perf_counter() - th
@@ -634,7 +649,7 @@ def main() -> None:
             line["pcie_inclusive_matches_resident"] = bool(np.array_equal(host_out.view(np.int64), out.cpu().numpy()))
         if world == 1 and not args.no_cpu_baseline and args.luts == 1:
             cores = min(16, os.cpu_count() or 1)
-            sample = cts[: min(count, CPU_SAMPLE)].cpu().numpy().view(np.uint64)
+            sample = cts[: min(count, cpu_sample)].cpu().numpy().view(np.uint64)
             line["cpu_baseline"], cpu_out = cpu_baseline(p, bsk, ksk, lut, sample, cores)
             # parity on the sample: the GPU and the CPU restatement must decrypt identically
             dec_cpu = cks.decrypt_message_and_carry_batch(cpu_out)

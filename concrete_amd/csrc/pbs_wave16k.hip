@@ -13,9 +13,9 @@
 //     512 a + t and transforms them in registers (radix 16, the twist folded into its input and
 //     output factors); ONE transposition through a 128 KB LDS image hands wave w the two
 //     512-point sub-transforms 2w and 2w + 1, which run on that wave alone, eight points per
-//     lane, with every lane exchange in registers (v_permlane32_swap, v_permlane16_swap, row
-//     shifts, quad permutes). A transform costs two workgroup barriers, around the
-//     transposition, and 256 KB of LDS traffic.
+//     lane: the exchange of lane bits 5:3 in registers (v_permlane32_swap, v_permlane16_swap, row
+//     shifts), that of lane bits 2:0 through the image row the wave has just read (or is about to
+//     write). A transform costs two workgroup barriers, around the transposition.
 //   * The Fourier-domain sums of both output columns stay in registers for the whole CMUX
 //     (2 x 16 complex values per thread); the key (1 MB per CMUX for two levels) streams from
 //     the L2 into the multiply-accumulate of each sub-transform.
@@ -34,6 +34,10 @@ namespace camd {
 namespace {
 
 namespace w16 {
+
+#ifndef W16_KEY_AUX
+#define W16_KEY_AUX 0   // cache-policy bits of the key loads (A/B builds)
+#endif
 
 constexpr int N = 16384, M = 8192, LOGN = 14, LOGM = 13;
 constexpr int THREADS = 512, PTS = 16;
@@ -111,78 +115,27 @@ __device__ __forceinline__ void dft16(double2 (&x)[16]) {
   for (int k = 0; k < 16; k++) x[k] = y[k];
 }
 
-// ---- lane exchanges of the 512-point sub-transforms, all in registers ----
-// value of a quad permutation of `v` (0x4E: lane ^ 2, 0xB1: lane ^ 1)
-template <int CTRL>
-__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-// register bit <-> lane bit PB (1 or 0): the values of lanes with that bit set in `a` trade places
-// with those of lanes with it clear in `b`
-template <int PB>
-__device__ __forceinline__ void swap_words_quad(uint32_t& a, uint32_t& b, bool lane_bit) {
-  constexpr int CTRL = PB == 1 ? 0x4E : 0xB1;
-  const uint32_t fb = quad_perm<CTRL>(b), fa = quad_perm<CTRL>(a);
-  a = lane_bit ? fb : a;
-  b = lane_bit ? b : fa;
-}
-template <int PB>
-__device__ __forceinline__ void swap_complex_quad(double2& a, double2& b, bool lane_bit) {
-  uint32_t a0 = (uint32_t)__double2loint(a.x), a1 = (uint32_t)__double2hiint(a.x);
-  uint32_t a2 = (uint32_t)__double2loint(a.y), a3 = (uint32_t)__double2hiint(a.y);
-  uint32_t b0 = (uint32_t)__double2loint(b.x), b1 = (uint32_t)__double2hiint(b.x);
-  uint32_t b2 = (uint32_t)__double2loint(b.y), b3 = (uint32_t)__double2hiint(b.y);
-  swap_words_quad<PB>(a0, b0, lane_bit); swap_words_quad<PB>(a1, b1, lane_bit);
-  swap_words_quad<PB>(a2, b2, lane_bit); swap_words_quad<PB>(a3, b3, lane_bit);
-  a = make_double2(__hiloint2double((int)a1, (int)a0), __hiloint2double((int)a3, (int)a2));
-  b = make_double2(__hiloint2double((int)b1, (int)b0), __hiloint2double((int)b3, (int)b2));
-}
-// x[q] of lane (h, lo) becomes what x[h] of lane (q, lo) was
-#ifdef W16_DEBUG_NOPS
-#define W16_STAGE_FENCE() asm volatile("s_nop 7\n s_nop 7" ::: "memory")
-#else
-#define W16_STAGE_FENCE()
-#endif
+// ---- lane exchanges of the 512-point sub-transforms ----
+// x[q] of lane (h, lo) becomes what x[h] of lane (q, lo) was: register bits <-> lane bits 5:3, in registers
 __device__ __forceinline__ void transpose_5_3(double2 (&x)[8]) {
-  W16_STAGE_FENCE();
 #pragma unroll
   for (int r = 0; r < 8; r++)
     if (!(r & 4)) swap_complex<5>(x[r], x[r | 4]);
-  W16_STAGE_FENCE();
 #pragma unroll
   for (int r = 0; r < 8; r++)
     if (!(r & 2)) swap_complex<4>(x[r], x[r | 2]);
-  W16_STAGE_FENCE();
 #pragma unroll
   for (int r = 0; r < 8; r++)
     if (!(r & 1)) swap_complex<3>(x[r], x[r | 1]);
-  W16_STAGE_FENCE();
 }
-// x[q] of lane (hi, l) becomes what x[l] of lane (hi, q) was
-__device__ __forceinline__ void transpose_2_0(double2 (&x)[8], int lane) {
-  const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
-  W16_STAGE_FENCE();
-#pragma unroll
-  for (int r = 0; r < 8; r++)
-    if (!(r & 4)) swap_complex<2>(x[r], x[r | 4]);
-  W16_STAGE_FENCE();
-#pragma unroll
-  for (int r = 0; r < 8; r++)
-    if (!(r & 2)) swap_complex_quad<1>(x[r], x[r | 2], b1);
-  W16_STAGE_FENCE();
-#pragma unroll
-  for (int r = 0; r < 8; r++)
-    if (!(r & 1)) swap_complex_quad<0>(x[r], x[r | 1], b0);
-  W16_STAGE_FENCE();
-}
-
-// The same exchange through 8 KB of LDS that belong to the wave alone (the image row of the
-// sub-transform it is working on): sixteen 16-byte accesses and as many address XORs instead of 160
-// lane-permute and select instructions; the vector ALU is what this kernel runs out of, the LDS is
-// idle. Lane (hi, l) stores register r in row 8 hi + (l ^ f), slot r ^ l, with f = bit 1 of hi:
-// the slot XOR keeps the eight lanes of a store group on different banks, f keeps the two lanes of a
-// 16-lane load group that share l on different halves of the 64 banks. No barrier: the LDS executes
-// one wave's accesses in order.
+// x[q] of lane (hi, l) becomes what x[l] of lane (hi, q) was: register bits <-> lane bits 2:0. In
+// registers this takes a row shift and two quad permutes with selects per word, 160 instructions;
+// it goes through 8 KB of LDS that belong to the wave alone instead (the image row of the
+// sub-transform it is working on): sixteen 16-byte accesses and as many address XORs. The vector
+// ALU is what this kernel runs out of, the LDS is mostly idle. Lane (hi, l) stores register r in
+// row 8 hi + (l ^ f), slot r ^ l, with f = bit 1 of hi: the slot XOR keeps the eight lanes of a
+// store group on different banks, f keeps the two lanes of a 16-lane load group that share l on
+// different halves of the 64 banks. No barrier: the LDS executes one wave's accesses in order.
 __device__ __forceinline__ void transpose_2_0_lds(double2 (&x)[8], int lane, double2* row) {
   const uint32_t hi = (uint32_t)lane >> 3, l = (uint32_t)lane & 7, f = (hi >> 1) & 1;
   char* base = (char*)row;
@@ -453,7 +406,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
               for (int g = 0; g < 8; g++) {
                 const auto w = __builtin_amdgcn_raw_buffer_load_b128(
                     key_rsrc, (int)(key_lane + (g & 3) * 1024),
-                    (int)(key_base + (uint32_t)c * (uint32_t)(M * sizeof(double2)) + e * 8192 + (g >> 2) * 4096), 0);
+                    (int)(key_base + (uint32_t)c * (uint32_t)(M * sizeof(double2)) + e * 8192 + (g >> 2) * 4096), W16_KEY_AUX);
                 kq[c][g] = as_double2(__builtin_bit_cast(v4u, w));
 #ifdef W16_TIMING_NO_KEY
                 kq[c][g] = make_double2(1e-3 * (double)(g + 1), 2e-3);

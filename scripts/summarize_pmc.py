@@ -16,7 +16,7 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("w4::pbs_kernel", "wave8_pbs_kernel", "wave_pbs_kernel", "block_pbs_kernel", "generic_pbs_kernel", "keyswitch_kernel", "ks_mfma_kernel",
+OURS = ("w16::pbs_kernel", "w4::pbs_kernel", "wave8_pbs_kernel", "wave_pbs_kernel", "block_pbs_kernel", "generic_pbs_kernel", "keyswitch_kernel", "ks_mfma_kernel",
         "ks_digits_kernel")
 
 
