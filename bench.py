@@ -293,7 +293,7 @@ def plumbing(args) -> None:
     census = rk.census()
     if rk.rank == 0:
         emit({
-            "metric": f"bootstraps/sec (node), {short_name}", "value": None, "unit": "bootstraps/s",
+            "metric": "bootstraps/sec (node), MESSAGE_2_CARRY_2", "value": None, "unit": "bootstraps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "none",
             "plumbing_only": True, **census,
