@@ -51,10 +51,18 @@ constexpr int TAB_TOTAL = TAB_TWS + TWS_COUNT;
 constexpr double TWIST4_RE[4] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173};
 constexpr double TWIST4_IM[4] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
 constexpr int PLANE = 4 * 64;
-template <typename T, int K>
-constexpr size_t slab_bytes() { return (size_t)(K + 1) * N * sizeof(T) + 2 * PLANE * sizeof(double); }
-template <typename T, int K>
-constexpr size_t lds_bytes() { return TWS_COUNT * sizeof(double2) + WAVES * slab_bytes<T, K>(); }
+// per wave: the accumulator ((k+1) N words of `word` bytes) and the two exchange planes
+template <int K>
+constexpr size_t slab_bytes(size_t word) { return (size_t)(K + 1) * N * word + 2 * PLANE * sizeof(double); }
+template <int K>
+constexpr size_t lds_bytes(size_t word) { return TWS_COUNT * sizeof(double2) + WAVES * slab_bytes<K>(word); }
+// The streamed form of a 64-bit single-level instance keeps the high dwords of the accumulator only
+// (the digits come from them; every CMUX rounds its increment at 2^-32 of the torus): half the LDS,
+// 4-byte gathers at 4-byte stride, and two workgroups fit a CU.
+template <typename T, int L, bool STREAM>
+struct AccWord { typedef T type; };
+template <>
+struct AccWord<uint64_t, 1, true> { typedef uint32_t type; };
 
 template <bool INV>
 __device__ __forceinline__ void dft4(double2 (&x)[4]) {
@@ -277,8 +285,12 @@ __device__ __forceinline__ int32_t next_digit(uint32_t& state) {
   return (int32_t)(res - (carry << BL));
 }
 
-template <typename T, int K, int L, int BL>
-__global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
+// STREAM: no key slab is parked; the key values of a CMUX come from the L2 inside its
+// multiply-accumulate, a few slabs ahead of their products. The wave then fits half the registers
+// of a SIMD, and two workgroups share a CU: while one wave sits in an LDS exchange or waits for a
+// key slab, its partner on the SIMD has the vector ALU.
+template <typename T, int K, int L, int BL, bool STREAM>
+__device__ __forceinline__ void pbs_body(const PbsLaunch<T>& a) {
   constexpr int R = K + 1;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
@@ -286,14 +298,22 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* slab = smem + TWS_COUNT * sizeof(double2) + (size_t)wave * slab_bytes<T, K>();
-  T* ct0 = (T*)slab;
-  double* sre = (double*)(slab + (size_t)R * N * sizeof(T));
+  typedef typename AccWord<T, L, STREAM>::type A;
+  constexpr bool HIGH = sizeof(A) < sizeof(T);      // accumulator of high dwords
+  char* slab = smem + TWS_COUNT * sizeof(double2) + (size_t)wave * slab_bytes<K>(sizeof(A));
+  A* ct0 = (A*)slab;
+  double* sre = (double*)(slab + (size_t)R * N * sizeof(A));
   double* sim = sre + PLANE;
   constexpr int S = R * L;          // forward streams: (level - 1) * R + row
   constexpr int NS = S * R;         // key slabs per iteration: [level][row][col], 4 KiB each
-  constexpr int NA = NS < 14 ? NS : 14;   // slabs parked in accumulation registers (at most 224 AGPRs)
+  constexpr int NA = STREAM ? 0 : (NS < 14 ? NS : 14);   // slabs parked in accumulation registers (at most 224 AGPRs)
+  constexpr int NAD = NA ? NA : 1, NVD = (!STREAM && NS > NA) ? NS - NA : 1;   // array extents
+#ifndef W4_AHEAD
+#define W4_AHEAD 4
+#endif
+  constexpr int AHEAD = W4_AHEAD;         // STREAM: key slabs in flight
   const uint32_t lane_off = (uint32_t)lane * 16u;
+  const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.fbsk, 0, (int)0x7FFFFFFF, 0x00020000);
   // persistent waves restart together per XCD (see wave_pbs_kernel_v2): key rows are then fetched
   // into each L2 once instead of once per drifting wave
   XcdRendezvous rendezvous;
@@ -310,7 +330,8 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
       const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
       for (int idx = lane; idx < R * N; idx += 64) {
         const int c = idx >> LOGN, j = idx & (N - 1);
-        ct0[idx] = rotated_coeff<T>(lut + (size_t)c * N, j, d0, N);
+        const T w = rotated_coeff<T>(lut + (size_t)c * N, j, d0, N);
+        if constexpr (HIGH) ct0[idx] = (A)(w >> 32); else ct0[idx] = (A)w;
       }
     }
     uint32_t i = 0;
@@ -319,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
       i++;
       a_cur = wave_uniform(in[i]);
     }
-    v4u bqa[NA][4];
+    v4u bqa[NAD][4];
 #pragma unroll
     for (int sl = 0; sl < NA; sl++)
 #pragma unroll
@@ -328,17 +349,29 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
     uint32_t a_hat = 0, cur = 0;
     for (;;) {
       double2 x[S][4];
-      v4u bqv[NS - NA > 0 ? NS - NA : 1][4];
+      v4u bqv[NVD][4];
+      v4u kst[STREAM ? AHEAD : 1][4];
+      uint32_t key_off = 0;
+      auto request = [&](int sl) {          // STREAM: slab sl of the current CMUX into its slot
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          kst[sl % AHEAD][g] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(
+              key_rsrc, (int)(lane_off + g * 1024), (int)(key_off + (uint32_t)sl * 4096u), 0));
+      };
       if (work) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          const T* p = ct0 + r * N;
+          const A* p = ct0 + r * N;
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const uint32_t j0 = 64 * q + lane, j1 = j0 + M;
             const uint32_t s0 = j0 - a_hat, s1 = j1 - a_hat;
-            const T rot0 = p[s0 & (N - 1)], rot1 = p[s1 & (N - 1)];
-            if constexpr (L == 1) {
+            const A rot0 = p[s0 & (N - 1)], rot1 = p[s1 & (N - 1)];
+            if constexpr (HIGH) {
+              const int32_t g0 = digit_of_rotated_difference32<BL, LOGN>(rot0, p[j0], s0);
+              const int32_t g1 = digit_of_rotated_difference32<BL, LOGN>(rot1, p[j1], s1);
+              x[r][q] = make_double2((double)g0, (double)g1);
+            } else if constexpr (L == 1) {
               const int32_t g0 = digit_of_rotated_difference<T, BL, LOGN>(rot0, p[j0], s0);
               const int32_t g1 = digit_of_rotated_difference<T, BL, LOGN>(rot1, p[j1], s1);
               x[r][q] = make_double2((double)g0, (double)g1);   // the twist is in the transform
@@ -355,9 +388,14 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
             }
           }
         }
+        if constexpr (STREAM) {
+          key_off = cur * (uint32_t)(NS * M * sizeof(double2));
+#pragma unroll
+          for (int sl = 0; sl < AHEAD && sl < NS; sl++) request(sl);
+        }
         // the slabs that do not fit the accumulation registers: requested now, needed after the transforms
 #pragma unroll
-        for (int sl = NA; sl < NS; sl++) {
+        for (int sl = NA; sl < (STREAM ? 0 : NS); sl++) {
           const char* base = (const char*)(a.fbsk + (size_t)cur * NS * M) + (size_t)sl * (M * sizeof(double2)) + 2048;
 #pragma unroll
           for (int g = 0; g < 4; g++)
@@ -374,6 +412,19 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
         for (int c = 0; c < R; c++)
 #pragma unroll
           for (int g = 0; g < 4; g++) acc[c][g] = make_double2(0.0, 0.0);
+      } else if constexpr (STREAM) {
+        // slabs in memory order [stream s][column c]: every (column, register) sum takes its products in
+        // the order of the parked form, so both forms give the same words
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++) {
+          const int sidx = sl / R, c = sl % R;
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const double2 kv = as_double2(kst[sl % AHEAD][g]);
+            acc[c][g] = sidx == 0 ? cmul(kv, x[0][g]) : cfma(kv, x[sidx][g], acc[c][g]);
+          }
+          if (sl + AHEAD < NS) request(sl + AHEAD);
+        }
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -399,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
       // key rows of the next active iteration (index i), if any
       const bool more = i < n;
       const char* ggsw = (const char*)(a.fbsk + (size_t)(more ? i : 0) * NS * M);
-      if (more) {
+      if (more && !STREAM) {
 #pragma unroll
         for (int sl = 0; sl < NA; sl++) {
           const char* base = ggsw + (size_t)sl * (M * sizeof(double2)) + 2048;
@@ -424,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
       fft256_inverse_tw<R>(acc, lane, tab, sre, sim);
 #pragma unroll
       for (int c = 0; c < R; c++) {
-        T* pc = ct0 + c * N;
+        A* pc = ct0 + c * N;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const uint32_t j0 = 64 * q + lane;
@@ -441,12 +492,24 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
     T* out = a.ct_out + ct * a.out_stride;
     for (int idx = lane; idx < K * N; idx += 64) {
       const int c = idx >> LOGN, j = idx & (N - 1);
-      const T* p = ct0 + c * N;
-      out[idx] = (j == 0) ? p[0] : (T)(T(0) - p[N - j]);
+      const A* p = ct0 + c * N;
+      const A w = (j == 0) ? p[0] : (A)(A(0) - p[N - j]);
+      if constexpr (HIGH) out[idx] = (T)w << 32; else out[idx] = (T)w;
     }
-    if (lane == 0) out[K * N] = ct0[K * N];
+    if (lane == 0) {
+      if constexpr (HIGH) out[K * N] = (T)ct0[K * N] << 32; else out[K * N] = (T)ct0[K * N];
+    }
     if ((size_t)(round + 1) * per_round < a.count) rendezvous.arrive_and_wait(round, lane);
   }
+}
+
+template <typename T, int K, int L, int BL>
+__global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
+  pbs_body<T, K, L, BL, false>(a);
+}
+template <typename T, int K, int L, int BL>
+__global__ __launch_bounds__(256, 2) void pbs_kernel_stream(PbsLaunch<T> a) {
+  pbs_body<T, K, L, BL, true>(a);
 }
 
 // Latency variant (see wave_pbs_kernel_lat): k+1 waves per ciphertext, wave c owning polynomial
@@ -667,9 +730,14 @@ inline void fill_tables(double2* t) {
 
 template <typename T, int K, int L, int BL>
 int launch(const PbsLaunch<T>& a, hipStream_t stream) {
-  constexpr size_t lds = lds_bytes<T, K>();
-  static_assert(lds <= 160 * 1024, "LDS budget exceeded");
-  auto kern = pbs_kernel<T, K, L, BL>;
+  static_assert(lds_bytes<K>(sizeof(T)) <= 160 * 1024, "LDS budget exceeded");
+  // CAMD_WAVE_SCHEDULE=1: the parked-key form, one workgroup per CU; default: the streamed form, two per CU
+  static const bool parked = []() {
+    const char* e = getenv("CAMD_WAVE_SCHEDULE");
+    return e && atoi(e) == 1;
+  }();
+  auto kern = parked ? pbs_kernel<T, K, L, BL> : pbs_kernel_stream<T, K, L, BL>;
+  const size_t lds = parked ? lds_bytes<K>(sizeof(T)) : lds_bytes<K>(sizeof(typename AccWord<T, L, true>::type));
   if (lds > 64 * 1024) CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int dev = 0, cus = 0;
   CAMD_HIP(hipGetDevice(&dev));
@@ -685,7 +753,8 @@ int launch(const PbsLaunch<T>& a, hipStream_t stream) {
     return CAMD_OK;
   }
   const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
-  const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;  // one wave per SIMD (512 registers)
+  const unsigned resident = (unsigned)cus * (parked ? 1u : 2u);    // workgroups a launch keeps on the chip
+  const unsigned persistent = cus > 0 && grid > resident ? resident : grid;
   if (persistent < grid) {
     if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
     CAMD_HIP(hipMemsetAsync(a.scratch, 0, RENDEZVOUS_BYTES, stream));

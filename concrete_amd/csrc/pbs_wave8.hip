@@ -142,17 +142,6 @@ __device__ __forceinline__ void fft512_inverse_multi1(double2 (&x)[S][8], int la
   }
 }
 
-// signed single-level digit of (wrapped ? -rot : rot) - own from the high dwords (see
-// digit_of_rotated_difference in wave_common.hpp; here the accumulator holds nothing else)
-template <int BL, int LOGN>
-__device__ __forceinline__ int32_t digit_of_rotated_difference32(uint32_t rot_hi, uint32_t own_hi, uint32_t shifted) {
-  const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int32_t)shifted, LOGN, 1);
-  constexpr uint32_t HALF = 1u << (32 - BL - 1);
-  uint32_t d;
-  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(rot_hi), "v"(m), "s"(HALF));
-  return (int32_t)(d - own_hi) >> (32 - BL);
-}
-
 template <typename T, int K, int BL>
 __global__ __launch_bounds__(512, 2) void wave8_pbs_kernel(PbsLaunch<T> a) {
   static_assert(sizeof(T) == 8 && BL <= 31, "64-bit torus whose digit lies in the high dword");

@@ -141,6 +141,16 @@ __device__ __forceinline__ int32_t digit_of_rotated_difference(T rot, T own, uin
   }
 }
 
+// the same digit for an accumulator that holds the high dwords only (32 bits per coefficient)
+template <int BL, int LOGN>
+__device__ __forceinline__ int32_t digit_of_rotated_difference32(uint32_t rot_hi, uint32_t own_hi, uint32_t shifted) {
+  const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int32_t)shifted, LOGN, 1);
+  constexpr uint32_t HALF = 1u << (32 - BL - 1);
+  uint32_t d;
+  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(rot_hi), "v"(m), "s"(HALF));
+  return (int32_t)(d - own_hi) >> (32 - BL);
+}
+
 // broadcast lane 0's value through SGPRs so that the compiler sees a wave-uniform value
 __device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
