@@ -55,7 +55,10 @@ constexpr int PLANE = 4 * 64;
 template <int K>
 constexpr size_t slab_bytes(size_t word) { return (size_t)(K + 1) * N * word + 2 * PLANE * sizeof(double); }
 template <int K>
-constexpr size_t lds_bytes(size_t word) { return TWS_COUNT * sizeof(double2) + WAVES * slab_bytes<K>(word); }
+constexpr size_t lds_bytes(size_t word, int waves = WAVES) {
+  return TWS_COUNT * sizeof(double2) + waves * slab_bytes<K>(word) + waves * sizeof(uint32_t);   // + progress words
+}
+constexpr int STREAM_WAVES = 8;   // waves per workgroup of the streamed form: two per SIMD, partners w and w ^ 4
 // The streamed form of a 64-bit single-level instance keeps the high dwords of the accumulator only
 // (the digits come from them; every CMUX rounds its increment at 2^-32 of the torus): half the LDS,
 // 4-byte gathers at 4-byte stride, and two workgroups fit a CU.
@@ -292,13 +295,16 @@ __device__ __forceinline__ int32_t next_digit(uint32_t& state) {
 template <typename T, int K, int L, int BL, bool STREAM>
 __device__ __forceinline__ void pbs_body(const PbsLaunch<T>& a) {
   constexpr int R = K + 1;
+  constexpr int WPB = STREAM ? STREAM_WAVES : WAVES;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
-  stage_tws(tab, a.tables, 256);
+  typedef typename AccWord<T, L, STREAM>::type A;
+  uint32_t* progress = (uint32_t*)(smem + TWS_COUNT * sizeof(double2) + (size_t)WPB * slab_bytes<K>(sizeof(A)));
+  stage_tws(tab, a.tables, WPB * 64);
+  if (STREAM && threadIdx.x < WPB) progress[threadIdx.x] = 0;   // a wave without a ciphertext never writes its word
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  typedef typename AccWord<T, L, STREAM>::type A;
   constexpr bool HIGH = sizeof(A) < sizeof(T);      // accumulator of high dwords
   char* slab = smem + TWS_COUNT * sizeof(double2) + (size_t)wave * slab_bytes<K>(sizeof(A));
   A* ct0 = (A*)slab;
@@ -318,13 +324,14 @@ __device__ __forceinline__ void pbs_body(const PbsLaunch<T>& a) {
   // into each L2 once instead of once per drifting wave
   XcdRendezvous rendezvous;
   if (a.scratch) rendezvous.enrol(a.scratch, lane);
-  const size_t per_round = (size_t)gridDim.x * WAVES;
+  const size_t per_round = (size_t)gridDim.x * WPB;
   uint32_t round = 0;
-  for (size_t ct = (size_t)blockIdx.x * WAVES + wave; ct < a.count; ct += per_round, round++) {
+  for (size_t ct = (size_t)blockIdx.x * WPB + wave; ct < a.count; ct += per_round, round++) {
     const T* in = a.ct_in + ct * a.in_stride;
     const uint32_t n = a.n;
     const uint32_t lut_id = checked_lut_id(a, ct);
     const T* lut = a.luts + (size_t)lut_id * (R * N);
+    if (STREAM && lane == 0) progress[wave] = 0;
     {
       const uint32_t b_hat = modswitch<T>(in[n], LOGN);
       const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
@@ -349,6 +356,19 @@ __device__ __forceinline__ void pbs_body(const PbsLaunch<T>& a) {
     uint32_t a_hat = 0, cur = 0;
     for (;;) {
       double2 x[S][4];
+      if constexpr (STREAM) {
+        // The SIMD's arbiter favours the older of its two waves; each wave publishes its iteration count
+        // and takes the higher priority while it is behind its partner, so that the pair stays in step
+        // (plain LDS accesses between compiler fences).
+        asm volatile("" ::: "memory");
+        if (lane == 0) progress[wave] = cur;
+        const uint32_t other = __builtin_amdgcn_readfirstlane(progress[wave ^ 4]);
+        asm volatile("" ::: "memory");
+        if (other > cur)
+          __builtin_amdgcn_s_setprio(2);
+        else
+          __builtin_amdgcn_s_setprio(0);
+      }
       v4u bqv[NVD][4];
       v4u kst[STREAM ? AHEAD : 1][4];
       uint32_t key_off = 0;
@@ -498,6 +518,7 @@ __device__ __forceinline__ void pbs_body(const PbsLaunch<T>& a) {
     }
     if (lane == 0) {
       if constexpr (HIGH) out[K * N] = (T)ct0[K * N] << 32; else out[K * N] = (T)ct0[K * N];
+      if (STREAM) progress[wave] = n;   // done: the partner keeps the higher priority until it is, too
     }
     if ((size_t)(round + 1) * per_round < a.count) rendezvous.arrive_and_wait(round, lane);
   }
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void pbs_kernel(PbsLaunch<T> a) {
   pbs_body<T, K, L, BL, false>(a);
 }
 template <typename T, int K, int L, int BL>
-__global__ __launch_bounds__(256, 2) void pbs_kernel_stream(PbsLaunch<T> a) {
+__global__ __launch_bounds__(64 * STREAM_WAVES, 2) void pbs_kernel_stream(PbsLaunch<T> a) {
   pbs_body<T, K, L, BL, true>(a);
 }
 
@@ -737,7 +758,9 @@ int launch(const PbsLaunch<T>& a, hipStream_t stream) {
     return e && atoi(e) == 1;
   }();
   auto kern = parked ? pbs_kernel<T, K, L, BL> : pbs_kernel_stream<T, K, L, BL>;
-  const size_t lds = parked ? lds_bytes<K>(sizeof(T)) : lds_bytes<K>(sizeof(typename AccWord<T, L, true>::type));
+  const size_t lds = parked ? lds_bytes<K>(sizeof(T))
+                            : lds_bytes<K>(sizeof(typename AccWord<T, L, true>::type), STREAM_WAVES);
+  static_assert(lds_bytes<K>(sizeof(typename AccWord<T, L, true>::type), STREAM_WAVES) <= 160 * 1024, "LDS budget exceeded");
   if (lds > 64 * 1024) CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int dev = 0, cus = 0;
   CAMD_HIP(hipGetDevice(&dev));
@@ -752,14 +775,14 @@ int launch(const PbsLaunch<T>& a, hipStream_t stream) {
     CAMD_HIP(hipGetLastError());
     return CAMD_OK;
   }
-  const unsigned grid = (unsigned)((a.count + WAVES - 1) / WAVES);
-  const unsigned resident = (unsigned)cus * (parked ? 1u : 2u);    // workgroups a launch keeps on the chip
-  const unsigned persistent = cus > 0 && grid > resident ? resident : grid;
+  const unsigned wpb = parked ? (unsigned)WAVES : (unsigned)STREAM_WAVES;
+  const unsigned grid = (unsigned)((a.count + wpb - 1) / wpb);
+  const unsigned persistent = cus > 0 && grid > (unsigned)cus ? (unsigned)cus : grid;   // one workgroup per CU
   if (persistent < grid) {
     if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel: arrival counters were not reserved");
     CAMD_HIP(hipMemsetAsync(a.scratch, 0, RENDEZVOUS_BYTES, stream));
   }
-  hipLaunchKernelGGL(kern, dim3(persistent), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(persistent), dim3(64 * wpb), lds, stream, a);
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;
 }
