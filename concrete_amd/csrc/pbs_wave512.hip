@@ -315,7 +315,7 @@ __device__ __forceinline__ void pbs_body(const PbsLaunch<T>& a) {
   constexpr int NA = STREAM ? 0 : (NS < 14 ? NS : 14);   // slabs parked in accumulation registers (at most 224 AGPRs)
   constexpr int NAD = NA ? NA : 1, NVD = (!STREAM && NS > NA) ? NS - NA : 1;   // array extents
 #ifndef W4_AHEAD
-#define W4_AHEAD 4
+#define W4_AHEAD 2
 #endif
   constexpr int AHEAD = W4_AHEAD;         // STREAM: key slabs in flight
   const uint32_t lane_off = (uint32_t)lane * 16u;
