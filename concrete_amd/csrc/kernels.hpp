@@ -163,10 +163,10 @@ bool wave_scratch_is_fixed(const camd_params& p);   // the scratch does not grow
 // the N = 16384 instances (pbs_wave16k.hip), reached through the wave_* functions
 bool wave16k_supported(const camd_params& p);
 size_t wave16k_tables_count();
-void wave16k_fill_tables(double2* t);
-size_t wave16k_scratch_bytes(unsigned* grid_out, size_t count, int cus);
+void wave16k_fill_tables(uint32_t N, double2* t);
+size_t wave16k_scratch_bytes(uint32_t N, unsigned* grid_out, size_t count, int cus);
 template <typename T>
-int wave16k_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream);
+int wave16k_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, uint32_t N, size_t polys, hipStream_t stream);
 template <typename T>
 int wave16k_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream);
 // the schedule with two waves per SIMD and a 32-bit accumulator (pbs_wave8.hip), reached through wave_launch_pbs

@@ -952,7 +952,7 @@ size_t wave_scratch_bytes(const camd_params& p, size_t count) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       cus = 256;
-    return wave16k_scratch_bytes(nullptr, count, cus);
+    return wave16k_scratch_bytes(p.polynomial_size, nullptr, count, cus);
   }
   return RENDEZVOUS_BYTES;
 }
@@ -988,7 +988,7 @@ bool wave_default(const camd_params& p) {
 }
 
 size_t wave_tables_count(uint32_t N) {
-  return N == 512 ? wave512_tables_count() : N == 16384 ? wave16k_tables_count() : (size_t)TAB_TOTAL;
+  return N == 512 ? wave512_tables_count() : N >= 8192 ? wave16k_tables_count() : (size_t)TAB_TOTAL;
 }
 
 void wave_fill_tables(uint32_t N, double2* t) {
@@ -996,8 +996,8 @@ void wave_fill_tables(uint32_t N, double2* t) {
     wave512_fill_tables(t);
     return;
   }
-  if (N == 16384) {
-    wave16k_fill_tables(t);
+  if (N >= 8192) {
+    wave16k_fill_tables(N, t);
     return;
   }
   for (int j = 0; j < 512; j++) {
@@ -1058,7 +1058,7 @@ int wave_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, 
     return wave512_bsk_to_fourier<T>(bsk_std, fbsk, tables, polys, stream);
   }
   if (wave16k_supported(p)) {
-    if constexpr (sizeof(T) == 8) return wave16k_bsk_to_fourier<T>(bsk_std, fbsk, tables, polys, stream);
+    if constexpr (sizeof(T) == 8) return wave16k_bsk_to_fourier<T>(bsk_std, fbsk, tables, p.polynomial_size, polys, stream);
     return fail(CAMD_EINVAL, "wave kernel: torus width mismatch");
   }
   const size_t lds = TAB_COUNT * sizeof(double2) + WAVES * 2 * PLANE * sizeof(double);
@@ -1072,7 +1072,7 @@ template <typename T>
 int wave_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
   if (a.count == 0) return CAMD_OK;
   if (a.N == 512) return wave512_launch_pbs<T>(a, stream);
-  if (a.N == 16384) return wave16k_launch_pbs<T>(a, stream);
+  if (a.N >= 8192) return wave16k_launch_pbs<T>(a, stream);
   if constexpr (sizeof(T) == 8) {
     if (a.N == 1024 && a.k == 2 && a.level == 1 && a.base_log == 23) return launch_instance<T, 2, 1, 23>(a, stream);
   } else {

@@ -39,8 +39,16 @@ namespace w16 {
 #define W16_KEY_AUX 0   // cache-policy bits of the key loads (A/B builds)
 #endif
 
-constexpr int N = 16384, M = 8192, LOGN = 14, LOGM = 13;
-constexpr int THREADS = 512, PTS = 16;
+constexpr int THREADS = 512;
+// sizes that follow from the polynomial size: N = 16384 (sixteen points per thread, two sub-transforms
+// per wave) or N = 8192 (eight points, one sub-transform)
+template <int LOGN_>
+struct Geo {
+  static constexpr int LOGN = LOGN_, N = 1 << LOGN_, M = N / 2, LOGM = LOGN_ - 1;
+  static constexpr int PTS = M / THREADS;    // points per thread of the radix step
+  static constexpr int SUBS = PTS / 8;       // 512-point sub-transforms per wave
+  static_assert(PTS == 16 || PTS == 8, "polynomial size without an instance");
+};
 
 // table buffer, in double2 entries: the folded constants of the 512-point sub-transforms (the LDS
 // image of the kernels) and the two per-thread factors of the four-step transform
@@ -48,16 +56,19 @@ constexpr int T_A = 0;                 // [pair 9][lane]: forward, second pass: 
 constexpr int T_B = T_A + 9 * 64;      // [pair 8][lo]:   input q carries e^{-2 pi i lo q/64}
 constexpr int T_C = T_B + 8 * 8;       // [pair 9][lane]: inverse, third pass: input b carries the conjugate of e^{-2 pi i lane b/512}
 constexpr int T_LDS = T_C + 9 * 64;    // entries staged in LDS
-constexpr int T_W = T_LDS;             // [t]: e^{i pi t/16384}
-constexpr int T_V = T_W + THREADS;     // [t]: e^{-i pi t/4096} = v
+constexpr int T_W = T_LDS;             // [t]: e^{i pi t/N}
+constexpr int T_V = T_W + THREADS;     // [t]: e^{-2 pi i t/(N/2)} = v
 constexpr int T_V2 = T_V + THREADS;    // [t]: v^2
 constexpr int T_V4 = T_V2 + THREADS;   // [t]: v^4
 constexpr int T_V8 = T_V4 + THREADS;   // [t]: v^8
 constexpr int T_TOTAL = T_V8 + THREADS;
 
-constexpr size_t IMAGE_BYTES = (size_t)PTS * THREADS * sizeof(double2);   // 128 KB
-constexpr size_t LDS_BYTES = T_LDS * sizeof(double2) + IMAGE_BYTES;
-constexpr size_t SLAB_BYTES = 2 * (size_t)N * sizeof(uint32_t);          // accumulator of one ciphertext (k + 1 = 2 polynomials)
+template <int LOGN>
+constexpr size_t image_bytes() { return (size_t)Geo<LOGN>::PTS * THREADS * sizeof(double2); }   // 128 KB or 64 KB
+template <int LOGN>
+constexpr size_t lds_bytes() { return T_LDS * sizeof(double2) + image_bytes<LOGN>(); }
+template <int LOGN>
+constexpr size_t slab_bytes() { return 2 * (size_t)Geo<LOGN>::N * sizeof(uint32_t); }   // accumulator of one ciphertext (k + 1 = 2 polynomials)
 
 // e^{i pi a/32}, a = 0..15: the per-register part of the twist
 __device__ __forceinline__ double2 twist16(int a) {
@@ -190,24 +201,34 @@ __device__ __forceinline__ void fft512_plain_inverse(double2 (&x)[8], int lane, 
   }
 }
 
-// The factors of the sixteen outputs of a thread's radix-16 step are f[k1] = w v^k1 with
-// w = e^{i pi t/16384} (the thread's share of the twist) and v = e^{-i pi t/4096} (the twiddle of the
-// four-step transform). They are formed as f[j + 4m] = (w v^j) (v^4m) from the tabulated w, v, v^2,
-// v^4 and v^8: no factor is more than three products away from correctly rounded values, and the
-// transform's rounding error stays next to that of a transform with fully tabulated twiddles.
+// per-register part of the twist, e^{i pi 512 a/N}, and the radix step itself, for either size
+template <int PTS>
+__device__ __forceinline__ double2 twist_reg(int a) { return twist16(PTS == 16 ? a : 2 * a); }
+template <int PTS, bool INV>
+__device__ __forceinline__ void dft_step(double2 (&z)[PTS]) {
+  if constexpr (PTS == 16) dft16<INV>(z); else dft8<INV>(z);
+}
+
+// The factors of the outputs of a thread's radix step are f[k1] = w v^k1 with w = e^{i pi t/N} (the
+// thread's share of the twist) and v = e^{-2 pi i t/(N/2)} (the twiddle of the four-step transform).
+// They are formed as f[j + 4m] = (w v^j) (v^4m) from the tabulated w, v, v^2, v^4 and v^8: no factor
+// is more than three products away from correctly rounded values, and the transform's rounding
+// error stays next to that of a transform with fully tabulated twiddles.
 struct StepFactors {
   double2 w, v, v2, v4, v8;
 };
+template <int PTS>
 __device__ __forceinline__ StepFactors load_step_factors(const double2* tables, int t) {
-  return {tables[T_W + t], tables[T_V + t], tables[T_V2 + t], tables[T_V4 + t], tables[T_V8 + t]};
+  return {tables[T_W + t], tables[T_V + t], tables[T_V2 + t], tables[T_V4 + t],
+          PTS == 16 ? tables[T_V8 + t] : make_double2(1.0, 0.0)};
 }
-template <bool CONJ>
-__device__ __forceinline__ void apply_step_factors(double2 (&z)[16], const StepFactors& f) {
+template <bool CONJ, int PTS>
+__device__ __forceinline__ void apply_step_factors(double2 (&z)[PTS], const StepFactors& f) {
   double2 b[4];
   b[0] = f.w; b[1] = cmul(f.w, f.v); b[2] = cmul(f.w, f.v2); b[3] = cmul(b[1], f.v2);
-  const double2 c[4] = {make_double2(1.0, 0.0), f.v4, f.v8, cmul(f.v4, f.v8)};
+  const double2 c[4] = {make_double2(1.0, 0.0), f.v4, f.v8, PTS == 16 ? cmul(f.v4, f.v8) : f.v8};
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
+  for (int m = 0; m < PTS / 4; m++) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const double2 g = m == 0 ? b[j] : cmul(b[j], c[m]);
@@ -216,36 +237,40 @@ __device__ __forceinline__ void apply_step_factors(double2 (&z)[16], const StepF
   }
 }
 
-// First half of the forward transform: z[a] = point 512 a + t (untwisted) in; out: the sixteen
-// values Y[k1] that go to row k1 of the transposition image.
-__device__ __forceinline__ void forward_step1(double2 (&z)[16], const StepFactors& f) {
+// First half of the forward transform: z[a] = point 512 a + t (untwisted) in; out: the values
+// Y[k1] that go to row k1 of the transposition image.
+template <int PTS>
+__device__ __forceinline__ void forward_step1(double2 (&z)[PTS], const StepFactors& f) {
 #ifdef W16_DEBUG_NO_STEP
   return;
 #endif
 #pragma unroll
-  for (int a = 1; a < 16; a++) z[a] = cmul(z[a], twist16(a));
-  dft16<false>(z);
-  apply_step_factors<false>(z, f);
+  for (int a = 1; a < PTS; a++) z[a] = cmul(z[a], twist_reg<PTS>(a));
+  dft_step<PTS, false>(z);
+  apply_step_factors<false, PTS>(z, f);
 }
-// Last half of the inverse transform: the sixteen values of image column t in, z[a] = 8192 *
-// (coefficient 512 a + t, coefficient 512 a + t + 8192) out (the key carries the 1/8192).
-__device__ __forceinline__ void inverse_step2(double2 (&z)[16], const StepFactors& f) {
+// Last half of the inverse transform: the values of image column t in, z[a] = N/2 *
+// (coefficient 512 a + t, coefficient 512 a + t + N/2) out (the key carries the 1/(N/2)).
+template <int PTS>
+__device__ __forceinline__ void inverse_step2(double2 (&z)[PTS], const StepFactors& f) {
 #ifdef W16_DEBUG_NO_STEP
   return;
 #endif
-  apply_step_factors<true>(z, f);
-  dft16<true>(z);
+  apply_step_factors<true, PTS>(z, f);
+  dft_step<PTS, true>(z);
 #pragma unroll
-  for (int a = 1; a < 16; a++) z[a] = cmul_conj(z[a], twist16(a));
+  for (int a = 1; a < PTS; a++) z[a] = cmul_conj(z[a], twist_reg<PTS>(a));
 }
 
 // ---- key conversion: one workgroup per polynomial; spectrum in the order the bootstrap reads it:
-// [wave w][sub-transform e][register g][lane], frequency (2w + e) + 16 (64 g + 8 (lane & 7) + (lane >> 3)),
-// values scaled by 1/8192 ----
-template <typename T>
+// [wave w][sub-transform e][register g][lane], frequency (SUBS w + e) + PTS (64 g + 8 (lane & 7) + (lane >> 3)),
+// values scaled by 2^-64 / (N/2) ----
+template <typename T, int LOGN>
 __global__ __launch_bounds__(THREADS) void bsk_fourier_kernel(const T* __restrict__ bsk, double2* __restrict__ out,
                                                               const double2* __restrict__ tables, size_t polys) {
   using S = typename Torus<T>::Signed;
+  using G = Geo<LOGN>;
+  constexpr int N = G::N, M = G::M, PTS = G::PTS, SUBS = G::SUBS;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
   double2* img = (double2*)(smem + T_LDS * sizeof(double2));
@@ -253,39 +278,42 @@ __global__ __launch_bounds__(THREADS) void bsk_fourier_kernel(const T* __restric
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const T* poly = bsk + (size_t)blockIdx.x * N;
   const double scale = 0x1.0p-64;
-  double2 z[16];
+  double2 z[PTS];
 #pragma unroll
-  for (int a = 0; a < 16; a++) {
+  for (int a = 0; a < PTS; a++) {
     const int j = 512 * a + t;
     z[a] = make_double2(signed_to_double((S)poly[j]) * scale, signed_to_double((S)poly[j + M]) * scale);
   }
-  forward_step1(z, load_step_factors(tables, t));
+  forward_step1<PTS>(z, load_step_factors<PTS>(tables, t));
 #pragma unroll
-  for (int k = 0; k < 16; k++) img[k * THREADS + t] = z[k];
+  for (int k = 0; k < PTS; k++) img[k * THREADS + t] = z[k];
   __syncthreads();
-  double2* dst = out + (size_t)blockIdx.x * M + (size_t)wave * 1024;
+  double2* dst = out + (size_t)blockIdx.x * M + (size_t)wave * (SUBS * 512);
 #pragma unroll
-  for (int e = 0; e < 2; e++) {
+  for (int e = 0; e < SUBS; e++) {
     double2 x[8];
 #pragma unroll
-    for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
-    fft512_plain_forward(x, lane, tab, img + (2 * wave + e) * THREADS);
+    for (int g = 0; g < 8; g++) x[g] = img[(SUBS * wave + e) * THREADS + 64 * g + lane];
+    fft512_plain_forward(x, lane, tab, img + (SUBS * wave + e) * THREADS);
 #pragma unroll
     for (int g = 0; g < 8; g++) dst[(e * 8 + g) * 64 + lane] = make_double2(x[g].x * (1.0 / M), x[g].y * (1.0 / M));
   }
 }
 
 // position of coefficient j in a polynomial of the slab: j and j + N/2 side by side
-__device__ __forceinline__ uint32_t slab_index(uint32_t j) { return ((j & (M - 1)) << 1) | (j >> LOGM); }
+template <int LOGN>
+__device__ __forceinline__ uint32_t slab_index(uint32_t j) { return ((j & (Geo<LOGN>::M - 1)) << 1) | (j >> Geo<LOGN>::LOGM); }
 
 #ifdef W16_DEBUG_KERNELS
-__device__ double2 dump_digits[4 * M], dump_sums[M], dump_back[M];
+__device__ double2 dump_digits[4 * 8192], dump_sums[8192], dump_back[8192];
 __device__ int dump_iteration = 0, dump_column = 0;
 #endif
 
-template <typename T, int L, int BL>
+template <typename T, int LOGN, int L, int BL>
 __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   static_assert(sizeof(T) == 8 && BL * L <= 30, "64-bit torus whose digits lie in the high dword");
+  using G = Geo<LOGN>;
+  constexpr int N = G::N, M = G::M, PTS = G::PTS, SUBS = G::SUBS;
   constexpr int R = 2;                    // k + 1
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   __syncthreads();
 
   const int t0 = threadIdx.x;
-  uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * SLAB_BYTES);   // [R][N] paired layout
+  uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * slab_bytes<LOGN>());   // [R][N] paired layout
   const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.fbsk, 0, (int)0x7FFFFFFF, 0x00020000);   // offsets are formed per iteration: the base moves with it
   const uint32_t n = a.n;
@@ -309,7 +337,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
       const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
       for (int idx = t0; idx < R * N; idx += THREADS) {
         const int c = idx >> LOGN, j = idx & (N - 1);
-        acc[c * N + slab_index(j)] = (uint32_t)(rotated_coeff<T>(lut + (size_t)c * N, j, d0, N) >> 32);
+        acc[c * N + slab_index<LOGN>(j)] = (uint32_t)(rotated_coeff<T>(lut + (size_t)c * N, j, d0, N) >> 32);
       }
     }
     __syncthreads();
@@ -320,11 +348,11 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
       const uint32_t a_hat = modswitch<T>(a_i, LOGN) & (2 * N - 1);
       // key of this iteration: [level][row][column][8192] complex
 
-      double2 S[R][2][8];   // Fourier sums: [column][sub-transform][register]
+      double2 S[R][SUBS][8];   // Fourier sums: [column][sub-transform][register]
 #pragma unroll
       for (int c = 0; c < R; c++)
 #pragma unroll
-        for (int e = 0; e < 2; e++)
+        for (int e = 0; e < SUBS; e++)
 #pragma unroll
           for (int g = 0; g < 8; g++) S[c][e][g] = make_double2(0.0, 0.0);
 
@@ -341,10 +369,10 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
           int t = t0;
           asm volatile("" : "+v"(t));
           const int lane = t & 63, wave = t >> 6;
-          const uint32_t key_lane = (uint32_t)lane * 16u + (uint32_t)wave * 16384u;
-          double2 z[16];
+          const uint32_t key_lane = (uint32_t)lane * 16u + (uint32_t)wave * (uint32_t)(SUBS * 8192);
+          double2 z[PTS];
 #pragma unroll
-          for (int q = 0; q < 16; q++) {
+          for (int q = 0; q < PTS; q++) {
             const uint32_t j0 = 512 * q + t;                                   // and j0 + M
             const uint32_t s0 = (j0 - a_hat) & (2 * N - 1);                     // rotated index of j0; that of j0 + M is s0 + M
 #ifdef W16_TIMING_NO_GATHER                                                     // timing experiments only: wrong results
@@ -380,22 +408,22 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
           }
 #ifdef W16_DEBUG_KERNELS
           if (blockIdx.x == 0 && (int)i == dump_iteration)
-            for (int q = 0; q < 16; q++) dump_digits[(r * 2 + (l - 1)) * M + 512 * q + t] = z[q];
+            for (int q = 0; q < PTS; q++) dump_digits[(r * 2 + (l - 1)) * M + 512 * q + t] = z[q];
 #endif
           __builtin_amdgcn_sched_barrier(0);
-          forward_step1(z, load_step_factors(a.tables, t));
+          forward_step1<PTS>(z, load_step_factors<PTS>(a.tables, t));
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();               // everyone is done with the image's previous content
 #pragma unroll
-          for (int k = 0; k < 16; k++) img[k * THREADS + t] = z[k];
+          for (int k = 0; k < PTS; k++) img[k * THREADS + t] = z[k];
           __syncthreads();
           // the two sub-transforms of this wave, one after the other, each followed by its products
           const uint32_t key_base = (uint32_t)(((size_t)i * L + (l - 1)) * R + r) * (uint32_t)(R * M * sizeof(double2));
 #pragma unroll
-          for (int e = 0; e < 2; e++) {
+          for (int e = 0; e < SUBS; e++) {
             double2 x[8];
 #pragma unroll
-            for (int g = 0; g < 8; g++) x[g] = img[(2 * wave + e) * THREADS + 64 * g + lane];
+            for (int g = 0; g < 8; g++) x[g] = img[(SUBS * wave + e) * THREADS + 64 * g + lane];
             fft512_plain_forward_head(x, lane, tab);
             __builtin_amdgcn_sched_barrier(0);
             // the key values of the first column are requested in front of the last exchange and pass, those of the second
@@ -415,7 +443,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             };
             request(0);
             __builtin_amdgcn_sched_barrier(0);
-            fft512_plain_forward_tail(x, lane, tab, img + (2 * wave + e) * THREADS);
+            fft512_plain_forward_tail(x, lane, tab, img + (SUBS * wave + e) * THREADS);
             __builtin_amdgcn_sched_barrier(0);
             request(1);
 #pragma unroll
@@ -436,27 +464,27 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
         __syncthreads();                 // everyone is done with the image's previous content
 #ifdef W16_DEBUG_KERNELS
         if (blockIdx.x == 0 && (int)i == dump_iteration && c == dump_column)
-          for (int e = 0; e < 2; e++)
+          for (int e = 0; e < SUBS; e++)
             for (int g = 0; g < 8; g++) dump_sums[wave * 1024 + (e * 8 + g) * 64 + lane] = S[c][e][g];
 #endif
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-          fft512_plain_inverse(S[c][e], lane, tab, img + (2 * wave + e) * THREADS);
+        for (int e = 0; e < SUBS; e++) {
+          fft512_plain_inverse(S[c][e], lane, tab, img + (SUBS * wave + e) * THREADS);
 #pragma unroll
-          for (int g = 0; g < 8; g++) img[(2 * wave + e) * THREADS + 64 * g + lane] = S[c][e][g];
+          for (int g = 0; g < 8; g++) img[(SUBS * wave + e) * THREADS + 64 * g + lane] = S[c][e][g];
         }
         __syncthreads();
-        double2 z[16];
+        double2 z[PTS];
 #pragma unroll
-        for (int k = 0; k < 16; k++) z[k] = img[k * THREADS + t];
-        inverse_step2(z, load_step_factors(a.tables, t));
+        for (int k = 0; k < PTS; k++) z[k] = img[k * THREADS + t];
+        inverse_step2<PTS>(z, load_step_factors<PTS>(a.tables, t));
 #ifdef W16_DEBUG_KERNELS
         if (blockIdx.x == 0 && (int)i == dump_iteration && c == dump_column)
-          for (int q = 0; q < 16; q++) dump_back[512 * q + t] = z[q];
+          for (int q = 0; q < PTS; q++) dump_back[512 * q + t] = z[q];
 #endif
         uint32_t* pc = acc + c * N;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
+        for (int q = 0; q < PTS; q++) {
           const uint32_t j0 = 512 * q + t;
 #ifdef W16_TIMING_NO_UPDATE_LOAD
           uint2 old = make_uint2(j0, j0 * 7u);
@@ -474,10 +502,10 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
     // sample extraction of coefficient 0; the low dwords are zero
     T* out = a.ct_out + ct * a.out_stride;
     for (int j = t0; j < N; j += THREADS) {
-      const uint32_t w = (j == 0) ? acc[slab_index(0)] : (uint32_t)(0u - acc[slab_index(N - j)]);
+      const uint32_t w = (j == 0) ? acc[slab_index<LOGN>(0)] : (uint32_t)(0u - acc[slab_index<LOGN>(N - j)]);
       out[j] = (T)w << 32;
     }
-    if (t0 == 0) out[N] = (T)acc[N + slab_index(0)] << 32;
+    if (t0 == 0) out[N] = (T)acc[N + slab_index<LOGN>(0)] << 32;
     __syncthreads();                     // the slab is rewritten by the next ciphertext
   }
 }
@@ -485,6 +513,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
 #ifdef W16_DEBUG_KERNELS
 // transform pieces on their own, for checks against a host transform (debug builds only)
 __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2* in, double2* out, const double2* tables) {
+  constexpr int PTS = 16;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
   double2* img = (double2*)(smem + T_LDS * sizeof(double2));
@@ -502,7 +531,7 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
     double2 z[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) z[a] = in[512 * a + t];
-    forward_step1(z, load_step_factors(tables, t));
+    forward_step1<PTS>(z, load_step_factors<PTS>(tables, t));
 #pragma unroll
     for (int k = 0; k < 16; k++) img[k * THREADS + t] = z[k];
     __syncthreads();
@@ -529,7 +558,7 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
     double2 z[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) z[k] = img[k * THREADS + t];
-    inverse_step2(z, load_step_factors(tables, t));
+    inverse_step2<PTS>(z, load_step_factors<PTS>(tables, t));
 #pragma unroll
     for (int a = 0; a < 16; a++) out[512 * a + t] = z[a];
   }
@@ -541,17 +570,18 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
 }  // namespace
 
 bool wave16k_supported(const camd_params& p) {
-  return p.torus_bits == 64 && p.polynomial_size == 16384 && p.glwe_dimension == 1 &&
-         p.pbs_level == 2 && p.pbs_base_log == 15;
+  if (p.torus_bits != 64 || p.glwe_dimension != 1) return false;
+  if (p.pbs_level == 2 && p.pbs_base_log == 15) return p.polynomial_size == 16384 || p.polynomial_size == 8192;
+  return p.polynomial_size == 8192 && p.pbs_level == 1 && p.pbs_base_log == 23;
 }
 size_t wave16k_tables_count() { return (size_t)w16::T_TOTAL; }
-size_t wave16k_scratch_bytes(unsigned* grid_out, size_t count, int cus) {
+size_t wave16k_scratch_bytes(uint32_t N, unsigned* grid_out, size_t count, int cus) {
   const unsigned grid = (unsigned)std::min<size_t>(count, (size_t)(cus > 0 ? cus : 1));
   if (grid_out) *grid_out = grid;
-  return (size_t)grid * w16::SLAB_BYTES;
+  return (size_t)grid * 2 * N * sizeof(uint32_t);
 }
 
-void wave16k_fill_tables(double2* t) {
+void wave16k_fill_tables(uint32_t N, double2* t) {
   // folded constants of a twiddled radix-8 pass (dft8_tw in wave1024.hpp): th[q] is the angle of input q
   auto fold = [&](double2* dst, int stride, const double (&th)[8], bool own_w0) {
     double c[8], tn[8];
@@ -585,54 +615,67 @@ void wave16k_fill_tables(double2* t) {
     fold(t + w16::T_B + lo, 8, th, false);
   }
   for (int i = 0; i < w16::THREADS; i++) {
-    const double aw = M_PI * (double)i / 16384.0;
+    const double aw = M_PI * (double)i / (double)N;
     t[w16::T_W + i] = make_double2(std::cos(aw), std::sin(aw));
     const int power_tables[4] = {w16::T_V, w16::T_V2, w16::T_V4, w16::T_V8};
     for (int s = 0; s < 4; s++) {
-      const double av = -M_PI * (double)(i << s) / 4096.0;
+      const double av = -2.0 * M_PI * (double)(i << s) / (double)(N / 2);
       t[power_tables[s] + i] = make_double2(std::cos(av), std::sin(av));
     }
   }
 }
 
 template <typename T>
-int wave16k_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, size_t polys, hipStream_t stream) {
-  auto kern = w16::bsk_fourier_kernel<T>;
-  CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3((unsigned)polys), dim3(w16::THREADS), w16::LDS_BYTES, stream, bsk_std, fbsk, tables, polys);
+int wave16k_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, uint32_t N, size_t polys, hipStream_t stream) {
+  if (N == 16384) {
+    auto kern = w16::bsk_fourier_kernel<T, 14>;
+    CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::lds_bytes<14>()));
+    hipLaunchKernelGGL(kern, dim3((unsigned)polys), dim3(w16::THREADS), w16::lds_bytes<14>(), stream, bsk_std, fbsk, tables, polys);
+  } else {
+    auto kern = w16::bsk_fourier_kernel<T, 13>;
+    CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::lds_bytes<13>()));
+    hipLaunchKernelGGL(kern, dim3((unsigned)polys), dim3(w16::THREADS), w16::lds_bytes<13>(), stream, bsk_std, fbsk, tables, polys);
+  }
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;
 }
+
+namespace {
+template <typename T, int LOGN, int L, int BL>
+int launch_instance16k(const PbsLaunch<T>& a, unsigned grid, hipStream_t stream) {
+  static_assert(w16::lds_bytes<LOGN>() <= 160 * 1024, "LDS budget exceeded");
+  auto kern = w16::pbs_kernel<T, LOGN, L, BL>;
+  CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::lds_bytes<LOGN>()));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(w16::THREADS), w16::lds_bytes<LOGN>(), stream, a);
+  CAMD_HIP(hipGetLastError());
+  return CAMD_OK;
+}
+}  // namespace
 
 template <typename T>
 int wave16k_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
   if constexpr (sizeof(T) == 8) {
     if (a.count == 0) return CAMD_OK;
-    if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel (N = 16384): the accumulator slabs were not reserved");
+    if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel (N >= 8192): the accumulator slabs were not reserved");
     int dev = 0, cus = 0;
     CAMD_HIP(hipGetDevice(&dev));
     CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     unsigned grid = 1;
-    wave16k_scratch_bytes(&grid, a.count, cus);
-    static_assert(w16::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
-    if (a.N == 16384 && a.k == 1 && a.level == 2 && a.base_log == 15) {
-      auto kern = w16::pbs_kernel<T, 2, 15>;
-      CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::LDS_BYTES));
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(w16::THREADS), w16::LDS_BYTES, stream, a);
-      CAMD_HIP(hipGetLastError());
-      return CAMD_OK;
-    }
+    wave16k_scratch_bytes(a.N, &grid, a.count, cus);
+    if (a.k == 1 && a.N == 16384 && a.level == 2 && a.base_log == 15) return launch_instance16k<T, 14, 2, 15>(a, grid, stream);
+    if (a.k == 1 && a.N == 8192 && a.level == 2 && a.base_log == 15) return launch_instance16k<T, 13, 2, 15>(a, grid, stream);
+    if (a.k == 1 && a.N == 8192 && a.level == 1 && a.base_log == 23) return launch_instance16k<T, 13, 1, 23>(a, grid, stream);
   }
-  return fail(CAMD_EINVAL, "wave kernel (N = 16384): no instance for this parameter set");
+  return fail(CAMD_EINVAL, "wave kernel (N >= 8192): no instance for this parameter set");
 }
 
-template int wave16k_bsk_to_fourier<uint64_t>(const uint64_t*, double2*, const double2*, size_t, hipStream_t);
+template int wave16k_bsk_to_fourier<uint64_t>(const uint64_t*, double2*, const double2*, uint32_t, size_t, hipStream_t);
 template int wave16k_launch_pbs<uint64_t>(const PbsLaunch<uint64_t>&, hipStream_t);
 template int wave16k_launch_pbs<uint32_t>(const PbsLaunch<uint32_t>&, hipStream_t);
 
 #ifdef W16_DEBUG_KERNELS
 extern "C" int camd_debug_w16_dump(int which, double* out_host) {
-  const size_t bytes = (size_t)w16::M * sizeof(double2);
+  const size_t bytes = (size_t)8192 * sizeof(double2);
   CAMD_HIP(hipDeviceSynchronize());
   if (which >= 100) {
     const int col = which - 100;
@@ -651,17 +694,17 @@ extern "C" int camd_debug_w16_dump(int which, double* out_host) {
 }
 extern "C" int camd_debug_w16(int mode, const double* in_host, double* out_host) {
   std::vector<double2> tables(w16::T_TOTAL);
-  wave16k_fill_tables(tables.data());
+  wave16k_fill_tables(16384, tables.data());
   double2 *d_in = nullptr, *d_out = nullptr, *d_tab = nullptr;
-  const size_t bytes = (size_t)w16::M * sizeof(double2);
+  const size_t bytes = (size_t)8192 * sizeof(double2);
   CAMD_HIP(hipMalloc(&d_in, bytes));
   CAMD_HIP(hipMalloc(&d_out, bytes));
   CAMD_HIP(hipMalloc(&d_tab, tables.size() * sizeof(double2)));
   CAMD_HIP(hipMemcpy(d_in, in_host, bytes, hipMemcpyHostToDevice));
   CAMD_HIP(hipMemcpy(d_tab, tables.data(), tables.size() * sizeof(double2), hipMemcpyHostToDevice));
   auto kern = w16::debug_kernel;
-  CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3(1), dim3(w16::THREADS), w16::LDS_BYTES, 0, mode, d_in, d_out, d_tab);
+  CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::lds_bytes<14>()));
+  hipLaunchKernelGGL(kern, dim3(1), dim3(w16::THREADS), w16::lds_bytes<14>(), 0, mode, d_in, d_out, d_tab);
   CAMD_HIP(hipGetLastError());
   CAMD_HIP(hipDeviceSynchronize());
   CAMD_HIP(hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost));
