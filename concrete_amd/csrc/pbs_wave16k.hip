@@ -442,10 +442,11 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
               }
             };
             request(0);
+            if constexpr (PTS == 8) request(1);     // (the smaller size has the registers for both)
             __builtin_amdgcn_sched_barrier(0);
             fft512_plain_forward_tail(x, lane, tab, img + (SUBS * wave + e) * THREADS);
             __builtin_amdgcn_sched_barrier(0);
-            request(1);
+            if constexpr (PTS != 8) request(1);
 #pragma unroll
             for (int c = 0; c < R; c++)
 #pragma unroll
