@@ -18,6 +18,7 @@
 // is pre-multiplied by 1/256. The exchange image is 4 rows of 64 values per plane, element
 // (r, lane) at r * 64 + (lane ^ (r << 2 * digit)): conflict-free for the lane groups of
 // ds_write_b64 and ds_read_b64 on both sides of every exchange (checked by enumeration).
+#include "lane_swap.hpp"
 #include "wave_common.hpp"
 
 namespace camd {
@@ -81,6 +82,22 @@ __device__ __forceinline__ void dft4(double2 (&x)[4]) {
 // transpose between the register index and base-4 digit DIGIT of the lane index, all streams
 template <int S, int DIGIT>
 __device__ __forceinline__ void exchange4(double2 (&x)[S][4], int lane, double* sre, double* sim) {
+#ifndef W4_REGISTER_DIGITS
+#define W4_REGISTER_DIGITS 2   // exchanges of lane digits >= this one run in registers
+#endif
+  if constexpr (DIGIT >= W4_REGISTER_DIGITS) {
+    // register bit 1 <-> lane bit 2 DIGIT + 1, register bit 0 <-> lane bit 2 DIGIT: for the upper two lane
+    // bits one v_permlane32_swap / v_permlane16_swap per register pair and dword, for bits 3:2 two row
+    // shifts; the LDS store path, which these kernels run out of first, is left to the other exchanges
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      swap_complex<2 * DIGIT + 1>(x[s][0], x[s][2]);
+      swap_complex<2 * DIGIT + 1>(x[s][1], x[s][3]);
+      swap_complex<2 * DIGIT>(x[s][0], x[s][1]);
+      swap_complex<2 * DIGIT>(x[s][2], x[s][3]);
+    }
+    return;
+  }
   constexpr int SH = 2 * DIGIT;
   const int d = (lane >> SH) & 3;
   const int rest = lane & ~(3 << SH);
