@@ -157,6 +157,41 @@ def test_edge_cases_2_2(gpu_ctx, variant):
     dk.close()
 
 
+@pytest.mark.parametrize("pname,count", [("PARAM_MESSAGE_2_CARRY_2", 301), ("PARAM_MESSAGE_1_CARRY_2", 521),
+                                         ("PARAM_MESSAGE_4_CARRY_4", 5), ("PARAM_MESSAGE_3_CARRY_4", 3)])
+def test_throughput_kernels_zero_mask_elements_and_ragged_batches(gpu_ctx, pname, count):
+    """The throughput schedules of the wave family (two waves per SIMD at N = 1024 and N = 512, the
+    workgroup-per-ciphertext kernel at N >= 8192) on batches that are no multiple of a workgroup, with
+    mask elements that are zero (the CMUX is skipped, as the reference skips it), a ciphertext whose
+    mask is all zero (a table look-up: exact) and two look-up tables: bootstrap alone through
+    camd_pbs_batch against the oracle's bootstrap, decryption for decryption."""
+    p = P.SHORTINT_BY_NAME[pname]
+    n = 10
+    ks = get_keys(p, 64, n_override=n)
+    o = ks.o
+    dk = device_key(gpu_ctx, ks, CAMD_PBS_WAVE)
+    msg, sup = p.message_modulus, p.message_modulus * p.carry_modulus
+    fs = [lambda x: x % msg, lambda x: (sup - 1 - x)]
+    luts = [o.generate_accumulator(f) for f in fs]
+    for l in luts:
+        dk.upload_lut(l)
+    delta = O.shortint_delta(p)
+    msgs = [(7 * i + 3) % sup for i in range(count)]
+    cts = np.stack([o.lwe_encrypt(ks.rng, ks.small, m * delta, ks.lwe_std) for m in msgs])
+    cts[0, :-1] = 0                       # a trivial ciphertext
+    cts[1, 0] = cts[1, 3] = 0             # zero mask elements, the first one among them
+    cts[2 % count, n - 1] = 0             # and the last
+    ids = (np.arange(count) % 2).astype(np.uint32)
+    got = dk.pbs(cts, ids)
+    acc = np.concatenate(luts).reshape(2, -1)
+    for i in list(range(min(count, 40))) + [count - 1]:
+        want = o.bootstrap(ks.fbsk, acc[ids[i]], cts[i])
+        assert O.shortint_decode(p, o.lwe_phase(ks.glwe, got[i])) == O.shortint_decode(p, o.lwe_phase(ks.glwe, want)), i
+        if i == 0:
+            assert np.array_equal(got[0], want)
+    dk.close()
+
+
 def test_device_pointer_entry_points(gpu_ctx):
     """Device-resident inputs (torch owns the memory), in-place output, explicit stream."""
     import torch
