@@ -420,8 +420,33 @@ def fheuint8_workload(args) -> None:
                 "expected_wrong_products": world * bootstraps * 2.0 ** -13.9,
                 "kernel_ms_per_launch": tm["pbs_ms"], "keyswitch_kernel_ms_per_launch": tm["ks_ms"]}
 
+    def timed_addition() -> dict:
+        """smart_add of operands whose blocks all hold carries (x + y + y, twice): both operands are
+        propagated block by block before the addition, the carry-propagation chain of the configuration."""
+        sks.reference_schedule = False
+
+        def step():
+            a = sks.unchecked_add(sks.unchecked_add(cx, cy), cy)
+            return sks.smart_add(a, a.clone())
+
+        step()
+        rk.barrier_sync()
+        l0, b0 = dk.launches, dk.bootstraps
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            total = step()
+        rk.barrier_sync()
+        elapsed = rk.max_over_ranks(time.perf_counter() - t0)
+        wrong = rk.sum_over_ranks(int(np.count_nonzero(cks.decrypt(total) != (2 * (x + 2 * y)) % 256)))
+        bootstraps = (dk.bootstraps - b0) / args.steps
+        return {"value": pairs * world * args.steps / elapsed, "unit": "additions/s", "ms_per_step": elapsed / args.steps * 1e3,
+                "launches_per_addition_batch": (dk.launches - l0) / args.steps,
+                "bootstraps_per_addition": bootstraps / pairs, "wrong_sums": wrong,
+                "expected_wrong_sums": world * bootstraps * 2.0 ** -13.9}
+
     fast = timed(False)
     ref = timed(True)
+    addition = timed_addition()
     census = rk.census()
     if rank == 0:
         emit({
@@ -436,6 +461,7 @@ def fheuint8_workload(args) -> None:
                        "bootstraps_per_multiplication": fast["bootstraps_per_multiplication"],
                        "schedule": "default: blocks without a carry are not bootstrapped by a propagation step, "
                                    "nor is the carry of an integer's last block"},
+            "addition_with_carry_propagation": addition,
             "reference_schedule": dict(ref, unit="multiplications/s",
                                        note="the same call issuing exactly the reference's bootstraps "
                                             "(radix_parallel/mul.rs:314-333, mod.rs:44-88)"),
