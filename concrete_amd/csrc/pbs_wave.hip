@@ -983,7 +983,9 @@ bool wave_default(const camd_params& p) {
     const char* e = getenv("CAMD_WAVE_16K");
     return e ? atoi(e) != 0 : true;
   }();
-  if (wave16k_supported(p)) return big;
+  // three levels of 2^11 at N = 16384: so little output noise that rounding the accumulator at 2^-32 would
+  // triple it; that instance is for callers that ask for it
+  if (wave16k_supported(p)) return big && p.pbs_level < 3;
   return wave_supported(p);
 }
 

@@ -311,7 +311,7 @@ __device__ int dump_iteration = 0, dump_column = 0;
 
 template <typename T, int LOGN, int L, int BL>
 __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
-  static_assert(sizeof(T) == 8 && BL * L <= 30, "64-bit torus whose digits lie in the high dword");
+  static_assert(sizeof(T) == 8 && BL * L <= 33 && BL * L != 31 && BL * L != 32, "64-bit torus whose digits lie in the high dword");
   using G = Geo<LOGN>;
   constexpr int N = G::N, M = G::M, PTS = G::PTS, SUBS = G::SUBS;
   constexpr int R = 2;                    // k + 1
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
         // L1/L2-resident slab) instead of keeping decomposition states alive across a transform: the sums
         // already take half of the register file. Balanced digits, lowest level first.
         const uint32_t* p = acc + r * N;
-#pragma unroll
+#pragma unroll L == 3 ? 1 : L          // (three levels: one copy of the body, or the registers run out)
         for (int l = L; l >= 1; l--) {
           // the thread index is made opaque per transform: indices that do not change from one gather to the
           // next are recomputed then, where hoisting them would cost registers that are not there
@@ -389,25 +389,34 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             // only, so a tie is one case in 2^(32 - BL L), not one in 2^32 as with 64-bit words: ties go to
             // the even neighbour (and the negation is exact) so that the rounding has no mean, which a
             // binary key would add up coherently over the N/2 coefficients it selects.
-            constexpr int DROP = 32 - BL * L;
-            constexpr uint32_t BELOW_HALF = (1u << (DROP - 1)) - 1u;
+            // When the levels ask for more bits than the 32 the accumulator keeps (three levels of 11), the
+            // difference is decomposed exactly and the lowest level's digit has SHORT bits fewer: its
+            // values are multiples of 2^SHORT.
+            constexpr int SHORT = BL * L > 32 ? BL * L - 32 : 0;
+            constexpr int DROP = BL * L > 32 ? 0 : 32 - BL * L;
             const uint32_t u0 = ((r0 ^ m0) - m0) - own.x, u1 = ((r1 ^ m1) - m1) - own.y;
-            int32_t v0 = (int32_t)(u0 + BELOW_HALF + __builtin_amdgcn_ubfe(u0, DROP, 1)) >> DROP;
-            int32_t v1 = (int32_t)(u1 + BELOW_HALF + __builtin_amdgcn_ubfe(u1, DROP, 1)) >> DROP;
+            int32_t v0 = (int32_t)u0, v1 = (int32_t)u1;
+            if constexpr (DROP > 0) {
+              constexpr uint32_t BELOW_HALF = (1u << (DROP > 0 ? DROP - 1 : 0)) - 1u;
+              v0 = (int32_t)(u0 + BELOW_HALF + __builtin_amdgcn_ubfe(u0, DROP, 1)) >> DROP;
+              v1 = (int32_t)(u1 + BELOW_HALF + __builtin_amdgcn_ubfe(u1, DROP, 1)) >> DROP;
+            }
 #pragma unroll
             for (int m = L; m > l; m--) {                                        // strip the digits below level l
-              v0 = (v0 - (int32_t)__builtin_amdgcn_sbfe(v0, 0, BL)) >> BL;
-              v1 = (v1 - (int32_t)__builtin_amdgcn_sbfe(v1, 0, BL)) >> BL;
+              const int width = m == L ? BL - SHORT : BL;
+              v0 = (v0 - (int32_t)__builtin_amdgcn_sbfe(v0, 0, width)) >> width;
+              v1 = (v1 - (int32_t)__builtin_amdgcn_sbfe(v1, 0, width)) >> width;
             }
             if (l > 1) {
-              v0 = (int32_t)__builtin_amdgcn_sbfe(v0, 0, BL);
-              v1 = (int32_t)__builtin_amdgcn_sbfe(v1, 0, BL);
+              const int width = l == L ? BL - SHORT : BL, scale = l == L ? SHORT : 0;
+              v0 = (int32_t)__builtin_amdgcn_sbfe(v0, 0, width) << scale;
+              v1 = (int32_t)__builtin_amdgcn_sbfe(v1, 0, width) << scale;
             }
             z[q] = make_double2((double)v0, (double)v1);
             if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four points' loads in flight at a time: registers are short
           }
 #ifdef W16_DEBUG_KERNELS
-          if (blockIdx.x == 0 && (int)i == dump_iteration)
+          if (L == 2 && blockIdx.x == 0 && (int)i == dump_iteration)
             for (int q = 0; q < PTS; q++) dump_digits[(r * 2 + (l - 1)) * M + 512 * q + t] = z[q];
 #endif
           __builtin_amdgcn_sched_barrier(0);
@@ -573,6 +582,7 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
 bool wave16k_supported(const camd_params& p) {
   if (p.torus_bits != 64 || p.glwe_dimension != 1) return false;
   if (p.pbs_level == 2 && p.pbs_base_log == 15) return p.polynomial_size == 16384 || p.polynomial_size == 8192;
+  if (p.pbs_level == 3 && p.pbs_base_log == 11) return p.polynomial_size == 16384;
   return p.polynomial_size == 8192 && p.pbs_level == 1 && p.pbs_base_log == 23;
 }
 size_t wave16k_tables_count() { return (size_t)w16::T_TOTAL; }
@@ -664,6 +674,7 @@ int wave16k_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
     unsigned grid = 1;
     wave16k_scratch_bytes(a.N, &grid, a.count, cus);
     if (a.k == 1 && a.N == 16384 && a.level == 2 && a.base_log == 15) return launch_instance16k<T, 14, 2, 15>(a, grid, stream);
+    if (a.k == 1 && a.N == 16384 && a.level == 3 && a.base_log == 11) return launch_instance16k<T, 14, 3, 11>(a, grid, stream);
     if (a.k == 1 && a.N == 8192 && a.level == 2 && a.base_log == 15) return launch_instance16k<T, 13, 2, 15>(a, grid, stream);
     if (a.k == 1 && a.N == 8192 && a.level == 1 && a.base_log == 23) return launch_instance16k<T, 13, 1, 23>(a, grid, stream);
   }

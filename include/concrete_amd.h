@@ -64,6 +64,8 @@ typedef struct camd_params {
  * instance (shortint: N = 1024 with k = 2, N = 512 with k = 3, N = 16384 and N = 8192 with k = 1 and
  * two levels of base 2^15, N = 8192 with k = 1 and one level of base 2^23; the two boolean parameter
  * sets, 32-bit torus: N = 512, k = 2, two levels; N = 1024, k = 1, three levels) and BLOCK otherwise.
+ * (N = 16384 with three levels of base 2^11 has a WAVE instance that AUTO does not select: the 32-bit
+ * accumulator would be most of that set's small output noise.)
  * The shortint instances keep 32 bits per accumulator coefficient (N = 1024 and N = 512: in large
  * batches; N >= 8192: always): the ciphertexts they return have zero low dwords, and each
  * blind-rotation step is rounded at 2^-32 of the torus (far below the output noise; part of the

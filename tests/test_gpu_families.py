@@ -441,10 +441,10 @@ def test_largest_polynomial_full_size_bit_exact(gpu_ctx, full_size_keys, pname, 
     dk.close()
 
 
-@pytest.mark.parametrize("pname", ["PARAM_MESSAGE_4_CARRY_4", "PARAM_MESSAGE_3_CARRY_4", "PARAM_MESSAGE_7_CARRY_0"])
+@pytest.mark.parametrize("pname", ["PARAM_MESSAGE_4_CARRY_4", "PARAM_MESSAGE_1_CARRY_7", "PARAM_MESSAGE_3_CARRY_4", "PARAM_MESSAGE_7_CARRY_0"])
 def test_largest_polynomial_full_size_throughput_kernel(gpu_ctx, full_size_keys, pname):
-    """PARAM_MESSAGE_4_CARRY_4 (N = 16384), 3_4 (N = 8192, two levels) and 7_0 (N = 8192, one level) at
-    their full LWE dimension through the kernel CAMD_PBS_AUTO selects for them
+    """PARAM_MESSAGE_4_CARRY_4 (N = 16384), 1_7 (N = 16384, three levels), 3_4 (N = 8192, two levels) and
+    7_0 (N = 8192, one level) at their full LWE dimension through the kernel CAMD_PBS_AUTO selects for them
     (pbs_wave16k.hip): 2048 fresh ciphertexts over the whole message space must decrypt to
     f(m), and the variance of the output phase error must stay within the predicted figure and
     next to the reference algorithm's on the same inputs. The reference values come from the
@@ -462,9 +462,13 @@ def test_largest_polynomial_full_size_throughput_kernel(gpu_ctx, full_size_keys,
 
     p, small, glwe, bsk, ksk = full_size_keys(pname)
     o = O.Oracle(p, 64)
-    dk = DeviceServerKey.from_standard_keys(gpu_ctx, p, bsk, ksk, variant=CAMD_PBS_AUTO)
+    # 1_7 (three levels of 2^11) has so little output noise that the accumulator's rounding is most of it:
+    # CAMD_PBS_AUTO keeps the bit-exact kernel there, and the instance is tested as what it is, on request
+    three_levels = p.pbs_level == 3
+    dk = DeviceServerKey.from_standard_keys(gpu_ctx, p, bsk, ksk, variant=CAMD_PBS_WAVE if three_levels else CAMD_PBS_AUTO)
     assert dk.variant == CAMD_PBS_WAVE
-    ref = DeviceServerKey.from_standard_keys(gpu_ctx, p, bsk, ksk, variant=CAMD_PBS_BLOCK)
+    ref = DeviceServerKey.from_standard_keys(gpu_ctx, p, bsk, ksk, variant=CAMD_PBS_AUTO if three_levels else CAMD_PBS_BLOCK)
+    assert ref.variant == CAMD_PBS_BLOCK
     msg, sup = p.message_modulus, p.message_modulus * p.carry_modulus
     lut = o.generate_accumulator(lambda x: x % msg)
     dk.upload_lut(lut)
@@ -480,8 +484,10 @@ def test_largest_polynomial_full_size_throughput_kernel(gpu_ctx, full_size_keys,
     accumulator_rounding = n * (1.0 + k * N / 2.0) * 2.0 ** -64 / 12.0
     bound = gadget + fft_variance(p, o) + accumulator_rounding
     nearest = lambda ph: ((ph + np.uint64(delta // 2)) // np.uint64(delta)) * np.uint64(delta)
+    # the ratio to the reference arithmetic may exceed one by the accumulator's share of the prediction
+    upper = 1.15 * bound / (bound - accumulator_rounding)
     near_g, near_w = check_noise_variance(64, count, count, bound, gadget, got, want, glwe, nearest, pname,
-                                           ratio_bar=(0.55, 1.15))
+                                           ratio_bar=(0.55, upper))
     dec_g, dec_w = (near_g // np.uint64(delta)) % np.uint64(2 * sup), (near_w // np.uint64(delta)) % np.uint64(2 * sup)
     assert np.array_equal(dec_g, dec_w)
     # a ciphertext both kernels decode alike but not to f(m) is the parameter set's own failure rate at
@@ -495,10 +501,10 @@ def test_largest_polynomial_full_size_throughput_kernel(gpu_ctx, full_size_keys,
 
 
 @pytest.mark.parametrize("n", [1, 7])
-@pytest.mark.parametrize("pname", ["PARAM_MESSAGE_4_CARRY_4", "PARAM_MESSAGE_3_CARRY_4", "PARAM_MESSAGE_7_CARRY_0"])
+@pytest.mark.parametrize("pname", ["PARAM_MESSAGE_4_CARRY_4", "PARAM_MESSAGE_1_CARRY_7", "PARAM_MESSAGE_3_CARRY_4", "PARAM_MESSAGE_7_CARRY_0"])
 def test_wave_kernel_largest_polynomial_short(gpu_ctx, pname, n):
-    """The throughput kernel of the N >= 8192 classes (pbs_wave16k.hip: N = 16384 with two levels,
-    N = 8192 with two levels and with one) on a shortened LWE dimension: one CMUX pins the
+    """The throughput kernel of the N >= 8192 classes (pbs_wave16k.hip: N = 16384 with two and three
+    levels, N = 8192 with two levels and with one) on a shortened LWE dimension: one CMUX pins the
     transform, the key layout and the digits against the oracle almost word for word (the f64
     results differ in their last bits only, and nothing has diverged yet); a few CMUXes must
     decrypt like the oracle with a phase error far inside the decoding margin.
