@@ -990,7 +990,7 @@ bool wave_default(const camd_params& p) {
 }
 
 size_t wave_tables_count(uint32_t N) {
-  return N == 512 ? wave512_tables_count() : N >= 8192 ? wave16k_tables_count() : (size_t)TAB_TOTAL;
+  return N == 512 ? wave512_tables_count() : N >= 2048 ? wave16k_tables_count() : (size_t)TAB_TOTAL;
 }
 
 void wave_fill_tables(uint32_t N, double2* t) {
@@ -998,7 +998,7 @@ void wave_fill_tables(uint32_t N, double2* t) {
     wave512_fill_tables(t);
     return;
   }
-  if (N >= 8192) {
+  if (N >= 2048) {
     wave16k_fill_tables(N, t);
     return;
   }
@@ -1074,7 +1074,7 @@ template <typename T>
 int wave_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
   if (a.count == 0) return CAMD_OK;
   if (a.N == 512) return wave512_launch_pbs<T>(a, stream);
-  if (a.N >= 8192) return wave16k_launch_pbs<T>(a, stream);
+  if (a.N >= 2048) return wave16k_launch_pbs<T>(a, stream);
   if constexpr (sizeof(T) == 8) {
     if (a.N == 1024 && a.k == 2 && a.level == 1 && a.base_log == 23) return launch_instance<T, 2, 1, 23>(a, stream);
   } else {

@@ -40,14 +40,18 @@ namespace w16 {
 #endif
 
 constexpr int THREADS = 512;
-// sizes that follow from the polynomial size: N = 16384 (sixteen points per thread, two sub-transforms
-// per wave) or N = 8192 (eight points, one sub-transform)
+// Sizes that follow from the polynomial size. A polynomial's transform has N/1024 rows of 512 points;
+// a workgroup always works on eight rows or sixteen: one ciphertext at N = 16384 (sixteen points per
+// thread, two sub-transforms per wave) and N = 8192 (eight points, one sub-transform), two
+// ciphertexts at N = 4096 (four points per thread and ciphertext) and four at N = 2048 (two points).
 template <int LOGN_>
 struct Geo {
   static constexpr int LOGN = LOGN_, N = 1 << LOGN_, M = N / 2, LOGM = LOGN_ - 1;
-  static constexpr int PTS = M / THREADS;    // points per thread of the radix step
-  static constexpr int SUBS = PTS / 8;       // 512-point sub-transforms per wave
-  static_assert(PTS == 16 || PTS == 8, "polynomial size without an instance");
+  static constexpr int PTS = M / THREADS;                  // points per thread and ciphertext: the radix of the step
+  static constexpr int CPW = PTS >= 8 ? 1 : 8 / PTS;       // ciphertexts per workgroup
+  static constexpr int SUBS = PTS >= 8 ? PTS / 8 : 1;      // 512-point sub-transforms per wave
+  static constexpr int ROWS = CPW * PTS;                   // rows of the transposition image
+  static_assert(PTS == 16 || PTS == 8 || PTS == 4 || PTS == 2, "polynomial size without an instance");
 };
 
 // table buffer, in double2 entries: the folded constants of the 512-point sub-transforms (the LDS
@@ -64,11 +68,13 @@ constexpr int T_V8 = T_V4 + THREADS;   // [t]: v^8
 constexpr int T_TOTAL = T_V8 + THREADS;
 
 template <int LOGN>
-constexpr size_t image_bytes() { return (size_t)Geo<LOGN>::PTS * THREADS * sizeof(double2); }   // 128 KB or 64 KB
+constexpr size_t image_bytes() { return (size_t)Geo<LOGN>::ROWS * THREADS * sizeof(double2); }   // 128 KB or 64 KB
 template <int LOGN>
 constexpr size_t lds_bytes() { return T_LDS * sizeof(double2) + image_bytes<LOGN>(); }
 template <int LOGN>
 constexpr size_t slab_bytes() { return 2 * (size_t)Geo<LOGN>::N * sizeof(uint32_t); }   // accumulator of one ciphertext (k + 1 = 2 polynomials)
+template <int LOGN>
+constexpr size_t group_slab_bytes() { return Geo<LOGN>::CPW * slab_bytes<LOGN>(); }   // of a workgroup's ciphertexts
 
 // e^{i pi a/32}, a = 0..15: the per-register part of the twist
 __device__ __forceinline__ double2 twist16(int a) {
@@ -201,12 +207,21 @@ __device__ __forceinline__ void fft512_plain_inverse(double2 (&x)[8], int lane, 
   }
 }
 
-// per-register part of the twist, e^{i pi 512 a/N}, and the radix step itself, for either size
+// per-register part of the twist, e^{i pi 512 a/N}, and the radix step itself, for every size
 template <int PTS>
-__device__ __forceinline__ double2 twist_reg(int a) { return twist16(PTS == 16 ? a : 2 * a); }
+__device__ __forceinline__ double2 twist_reg(int a) { return twist16(a * (16 / PTS)); }
 template <int PTS, bool INV>
 __device__ __forceinline__ void dft_step(double2 (&z)[PTS]) {
-  if constexpr (PTS == 16) dft16<INV>(z); else dft8<INV>(z);
+  if constexpr (PTS == 16) {
+    dft16<INV>(z);
+  } else if constexpr (PTS == 8) {
+    dft8<INV>(z);
+  } else if constexpr (PTS == 4) {
+    dft4<INV>(z[0], z[1], z[2], z[3]);
+  } else {
+    const double2 s = cadd(z[0], z[1]), d = csub(z[0], z[1]);
+    z[0] = s; z[1] = d;
+  }
 }
 
 // The factors of the outputs of a thread's radix step are f[k1] = w v^k1 with w = e^{i pi t/N} (the
@@ -219,8 +234,9 @@ struct StepFactors {
 };
 template <int PTS>
 __device__ __forceinline__ StepFactors load_step_factors(const double2* tables, int t) {
-  return {tables[T_W + t], tables[T_V + t], tables[T_V2 + t], tables[T_V4 + t],
-          PTS == 16 ? tables[T_V8 + t] : make_double2(1.0, 0.0)};
+  const double2 one = make_double2(1.0, 0.0);
+  return {tables[T_W + t], tables[T_V + t], PTS > 2 ? tables[T_V2 + t] : one, PTS > 4 ? tables[T_V4 + t] : one,
+          PTS > 8 ? tables[T_V8 + t] : one};
 }
 template <bool CONJ, int PTS>
 __device__ __forceinline__ void apply_step_factors(double2 (&z)[PTS], const StepFactors& f) {
@@ -228,12 +244,10 @@ __device__ __forceinline__ void apply_step_factors(double2 (&z)[PTS], const Step
   b[0] = f.w; b[1] = cmul(f.w, f.v); b[2] = cmul(f.w, f.v2); b[3] = cmul(b[1], f.v2);
   const double2 c[4] = {make_double2(1.0, 0.0), f.v4, f.v8, PTS == 16 ? cmul(f.v4, f.v8) : f.v8};
 #pragma unroll
-  for (int m = 0; m < PTS / 4; m++) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const double2 g = m == 0 ? b[j] : cmul(b[j], c[m]);
-      z[j + 4 * m] = CONJ ? cmul_conj(z[j + 4 * m], g) : cmul(z[j + 4 * m], g);
-    }
+  for (int k1 = 0; k1 < PTS; k1++) {
+    const int j = k1 & 3, m = k1 >> 2;
+    const double2 g = m == 0 ? b[j] : cmul(b[j], c[m]);
+    z[k1] = CONJ ? cmul_conj(z[k1], g) : cmul(z[k1], g);
   }
 }
 
@@ -263,7 +277,7 @@ __device__ __forceinline__ void inverse_step2(double2 (&z)[PTS], const StepFacto
 }
 
 // ---- key conversion: one workgroup per polynomial; spectrum in the order the bootstrap reads it:
-// [wave w][sub-transform e][register g][lane], frequency (SUBS w + e) + PTS (64 g + 8 (lane & 7) + (lane >> 3)),
+// [row = SUBS w + e][register g][lane], frequency row + PTS (64 g + 8 (lane & 7) + (lane >> 3)),
 // values scaled by 2^-64 / (N/2) ----
 template <typename T, int LOGN>
 __global__ __launch_bounds__(THREADS) void bsk_fourier_kernel(const T* __restrict__ bsk, double2* __restrict__ out,
@@ -289,6 +303,7 @@ __global__ __launch_bounds__(THREADS) void bsk_fourier_kernel(const T* __restric
   for (int k = 0; k < PTS; k++) img[k * THREADS + t] = z[k];
   __syncthreads();
   double2* dst = out + (size_t)blockIdx.x * M + (size_t)wave * (SUBS * 512);
+  if (SUBS * wave >= PTS) return;          // a polynomial of the small sizes has fewer rows than the workgroup has waves
 #pragma unroll
   for (int e = 0; e < SUBS; e++) {
     double2 x[8];
@@ -313,7 +328,7 @@ template <typename T, int LOGN, int L, int BL>
 __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   static_assert(sizeof(T) == 8 && BL * L <= 33 && BL * L != 31 && BL * L != 32, "64-bit torus whose digits lie in the high dword");
   using G = Geo<LOGN>;
-  constexpr int N = G::N, M = G::M, PTS = G::PTS, SUBS = G::SUBS;
+  constexpr int N = G::N, M = G::M, PTS = G::PTS, SUBS = G::SUBS, CPW = G::CPW;
   constexpr int R = 2;                    // k + 1
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
@@ -322,30 +337,43 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   __syncthreads();
 
   const int t0 = threadIdx.x;
-  uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * slab_bytes<LOGN>());   // [R][N] paired layout
+  uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * group_slab_bytes<LOGN>());   // [ciphertext][R][N] paired layout
   const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.fbsk, 0, (int)0x7FFFFFFF, 0x00020000);   // offsets are formed per iteration: the base moves with it
   const uint32_t n = a.n;
 
-  for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
-    const T* in = a.ct_in + ct * a.in_stride;
-    const uint32_t lut_id = checked_lut_id(a, ct);
-    const T* lut = a.luts + (size_t)lut_id * (R * N);
-    {
+  for (size_t group = blockIdx.x; group * CPW < a.count; group += gridDim.x) {
+    // the ciphertexts of this round; a slot past the end of the batch repeats the last ciphertext (its
+    // result is not written)
+    const T* in[CPW];
+#pragma unroll
+    for (int b = 0; b < CPW; b++) {
+      const size_t ct = group * CPW + b < a.count ? group * CPW + b : a.count - 1;
+      in[b] = a.ct_in + ct * a.in_stride;
+      const uint32_t lut_id = checked_lut_id(a, ct);
+      const T* lut = a.luts + (size_t)lut_id * (R * N);
       // acc <- lut * X^{-b_hat}, high dwords
-      const uint32_t b_hat = modswitch<T>(in[n], LOGN);
+      const uint32_t b_hat = modswitch<T>(in[b][n], LOGN);
       const uint32_t d0 = (2 * N - b_hat) & (2 * N - 1);
       for (int idx = t0; idx < R * N; idx += THREADS) {
         const int c = idx >> LOGN, j = idx & (N - 1);
-        acc[c * N + slab_index<LOGN>(j)] = (uint32_t)(rotated_coeff<T>(lut + (size_t)c * N, j, d0, N) >> 32);
+        acc[b * R * N + c * N + slab_index<LOGN>(j)] = (uint32_t)(rotated_coeff<T>(lut + (size_t)c * N, j, d0, N) >> 32);
       }
     }
     __syncthreads();
 
     for (uint32_t i = 0; i < n; i++) {
-      const T a_i = wave_uniform(in[i]);
-      if (a_i == 0) continue;            // the reference skips these iterations too
-      const uint32_t a_hat = modswitch<T>(a_i, LOGN) & (2 * N - 1);
+      // a mask element that is zero rotates by nothing: its digits are all zero and nothing is added;
+      // the CMUX is skipped when that holds for every ciphertext of the workgroup (the reference skips it too)
+      uint32_t a_hat[CPW];
+      bool any = false;
+#pragma unroll
+      for (int b = 0; b < CPW; b++) {
+        const T a_i = wave_uniform(in[b][i]);
+        any |= a_i != 0;
+        a_hat[b] = a_i == 0 ? 0u : (modswitch<T>(a_i, LOGN) & (2 * N - 1));
+      }
+      if (!any) continue;
       // key of this iteration: [level][row][column][8192] complex
 
       double2 S[R][SUBS][8];   // Fourier sums: [column][sub-transform][register]
@@ -361,7 +389,6 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
         // The rotated difference of row r is gathered once per level (16 points = 32 coefficients, from the
         // L1/L2-resident slab) instead of keeping decomposition states alive across a transform: the sums
         // already take half of the register file. Balanced digits, lowest level first.
-        const uint32_t* p = acc + r * N;
 #pragma unroll L == 3 ? 1 : L          // (three levels: one copy of the body, or the registers run out)
         for (int l = L; l >= 1; l--) {
           // the thread index is made opaque per transform: indices that do not change from one gather to the
@@ -369,12 +396,16 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
           int t = t0;
           asm volatile("" : "+v"(t));
           const int lane = t & 63, wave = t >> 6;
-          const uint32_t key_lane = (uint32_t)lane * 16u + (uint32_t)wave * (uint32_t)(SUBS * 8192);
-          double2 z[PTS];
+          // this wave's rows of a key polynomial (the waves of different ciphertexts read the same rows)
+          const uint32_t key_lane = (uint32_t)lane * 16u + (uint32_t)(CPW == 1 ? wave : wave % PTS) * (uint32_t)(SUBS * 8192);
+          double2 z[CPW][PTS];
+#pragma unroll
+          for (int b = 0; b < CPW; b++) {
+          const uint32_t* p = acc + b * R * N + r * N;
 #pragma unroll
           for (int q = 0; q < PTS; q++) {
             const uint32_t j0 = 512 * q + t;                                   // and j0 + M
-            const uint32_t s0 = (j0 - a_hat) & (2 * N - 1);                     // rotated index of j0; that of j0 + M is s0 + M
+            const uint32_t s0 = (j0 - a_hat[b]) & (2 * N - 1);                     // rotated index of j0; that of j0 + M is s0 + M
 #ifdef W16_TIMING_NO_GATHER                                                     // timing experiments only: wrong results
             const uint2 own = make_uint2(j0 * 2654435761u, s0 * 40503u), pr = make_uint2(s0 * 2246822519u, j0 * 3266489917u);
 #else
@@ -412,19 +443,25 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
               v0 = (int32_t)__builtin_amdgcn_sbfe(v0, 0, width) << scale;
               v1 = (int32_t)__builtin_amdgcn_sbfe(v1, 0, width) << scale;
             }
-            z[q] = make_double2((double)v0, (double)v1);
+            z[b][q] = make_double2((double)v0, (double)v1);
             if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four points' loads in flight at a time: registers are short
           }
+          }
 #ifdef W16_DEBUG_KERNELS
-          if (L == 2 && blockIdx.x == 0 && (int)i == dump_iteration)
-            for (int q = 0; q < PTS; q++) dump_digits[(r * 2 + (l - 1)) * M + 512 * q + t] = z[q];
+          if (L == 2 && CPW == 1 && blockIdx.x == 0 && (int)i == dump_iteration)
+            for (int q = 0; q < PTS; q++) dump_digits[((r * 2 + (l - 1)) * M + 512 * q + t) & (4 * 8192 - 1)] = z[0][q];
 #endif
           __builtin_amdgcn_sched_barrier(0);
-          forward_step1<PTS>(z, load_step_factors<PTS>(a.tables, t));
+          // (the factors are loaded where they are used, per ciphertext: held in a variable across the
+          // loop they are fetched early and cost the registers of the largest instance)
+#pragma unroll
+          for (int b = 0; b < CPW; b++) forward_step1<PTS>(z[b], load_step_factors<PTS>(a.tables, t));
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();               // everyone is done with the image's previous content
 #pragma unroll
-          for (int k = 0; k < PTS; k++) img[k * THREADS + t] = z[k];
+          for (int b = 0; b < CPW; b++)
+#pragma unroll
+            for (int k = 0; k < PTS; k++) img[(b * PTS + k) * THREADS + t] = z[b][k];
           __syncthreads();
           // the two sub-transforms of this wave, one after the other, each followed by its products
           const uint32_t key_base = (uint32_t)(((size_t)i * L + (l - 1)) * R + r) * (uint32_t)(R * M * sizeof(double2));
@@ -451,11 +488,11 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
               }
             };
             request(0);
-            if constexpr (PTS == 8) request(1);     // (the smaller size has the registers for both)
+            if constexpr (PTS <= 8) request(1);     // (the smaller sizes have the registers for both)
             __builtin_amdgcn_sched_barrier(0);
             fft512_plain_forward_tail(x, lane, tab, img + (SUBS * wave + e) * THREADS);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PTS != 8) request(1);
+            if constexpr (PTS > 8) request(1);
 #pragma unroll
             for (int c = 0; c < R; c++)
 #pragma unroll
@@ -475,7 +512,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
 #ifdef W16_DEBUG_KERNELS
         if (blockIdx.x == 0 && (int)i == dump_iteration && c == dump_column)
           for (int e = 0; e < SUBS; e++)
-            for (int g = 0; g < 8; g++) dump_sums[wave * 1024 + (e * 8 + g) * 64 + lane] = S[c][e][g];
+            for (int g = 0; g < 8; g++) dump_sums[(wave * 1024 + (e * 8 + g) * 64 + lane) & 8191] = S[c][e][g];
 #endif
 #pragma unroll
         for (int e = 0; e < SUBS; e++) {
@@ -484,38 +521,49 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
           for (int g = 0; g < 8; g++) img[(SUBS * wave + e) * THREADS + 64 * g + lane] = S[c][e][g];
         }
         __syncthreads();
-        double2 z[PTS];
+        double2 z[CPW][PTS];
 #pragma unroll
-        for (int k = 0; k < PTS; k++) z[k] = img[k * THREADS + t];
-        inverse_step2<PTS>(z, load_step_factors<PTS>(a.tables, t));
+        for (int b = 0; b < CPW; b++)
+#pragma unroll
+          for (int k = 0; k < PTS; k++) z[b][k] = img[(b * PTS + k) * THREADS + t];
+#pragma unroll
+        for (int b = 0; b < CPW; b++) inverse_step2<PTS>(z[b], load_step_factors<PTS>(a.tables, t));
 #ifdef W16_DEBUG_KERNELS
-        if (blockIdx.x == 0 && (int)i == dump_iteration && c == dump_column)
-          for (int q = 0; q < PTS; q++) dump_back[512 * q + t] = z[q];
+        if (CPW == 1 && blockIdx.x == 0 && (int)i == dump_iteration && c == dump_column)
+          for (int q = 0; q < PTS; q++) dump_back[(512 * q + t) & 8191] = z[0][q];
 #endif
-        uint32_t* pc = acc + c * N;
 #pragma unroll
-        for (int q = 0; q < PTS; q++) {
-          const uint32_t j0 = 512 * q + t;
+        for (int b = 0; b < CPW; b++) {
+          uint32_t* pc = acc + b * R * N + c * N;
+#pragma unroll
+          for (int q = 0; q < PTS; q++) {
+            const uint32_t j0 = 512 * q + t;
 #ifdef W16_TIMING_NO_UPDATE_LOAD
-          uint2 old = make_uint2(j0, j0 * 7u);
+            uint2 old = make_uint2(j0, j0 * 7u);
 #else
-          uint2 old = *(const uint2*)(pc + 2 * j0);
+            uint2 old = *(const uint2*)(pc + 2 * j0);
 #endif
-          old.x = torus_accumulate(old.x, z[q].x);
-          old.y = torus_accumulate(old.y, z[q].y);
-          *(uint2*)(pc + 2 * j0) = old;
+            old.x = torus_accumulate(old.x, z[b][q].x);
+            old.y = torus_accumulate(old.y, z[b][q].y);
+            *(uint2*)(pc + 2 * j0) = old;
+          }
         }
       }
       __syncthreads();                   // the next gather reads what other threads just wrote
     }
 
     // sample extraction of coefficient 0; the low dwords are zero
-    T* out = a.ct_out + ct * a.out_stride;
-    for (int j = t0; j < N; j += THREADS) {
-      const uint32_t w = (j == 0) ? acc[slab_index<LOGN>(0)] : (uint32_t)(0u - acc[slab_index<LOGN>(N - j)]);
-      out[j] = (T)w << 32;
+#pragma unroll
+    for (int b = 0; b < CPW; b++) {
+      if (group * CPW + b >= a.count) break;
+      const uint32_t* pb = acc + b * R * N;
+      T* out = a.ct_out + (group * CPW + b) * a.out_stride;
+      for (int j = t0; j < N; j += THREADS) {
+        const uint32_t w = (j == 0) ? pb[slab_index<LOGN>(0)] : (uint32_t)(0u - pb[slab_index<LOGN>(N - j)]);
+        out[j] = (T)w << 32;
+      }
+      if (t0 == 0) out[N] = (T)pb[N + slab_index<LOGN>(0)] << 32;
     }
-    if (t0 == 0) out[N] = (T)acc[N + slab_index<LOGN>(0)] << 32;
     __syncthreads();                     // the slab is rewritten by the next ciphertext
   }
 }
@@ -581,15 +629,17 @@ __global__ __launch_bounds__(THREADS) void debug_kernel(int mode, const double2*
 
 bool wave16k_supported(const camd_params& p) {
   if (p.torus_bits != 64 || p.glwe_dimension != 1) return false;
-  if (p.pbs_level == 2 && p.pbs_base_log == 15) return p.polynomial_size == 16384 || p.polynomial_size == 8192;
-  if (p.pbs_level == 3 && p.pbs_base_log == 11) return p.polynomial_size == 16384;
-  return p.polynomial_size == 8192 && p.pbs_level == 1 && p.pbs_base_log == 23;
+  const uint32_t N = p.polynomial_size;
+  if (p.pbs_level == 2 && p.pbs_base_log == 15) return N == 16384 || N == 8192 || N == 4096;
+  if (p.pbs_level == 3 && p.pbs_base_log == 11) return N == 16384;
+  return (N == 8192 || N == 4096 || N == 2048) && p.pbs_level == 1 && p.pbs_base_log == 23;
 }
 size_t wave16k_tables_count() { return (size_t)w16::T_TOTAL; }
 size_t wave16k_scratch_bytes(uint32_t N, unsigned* grid_out, size_t count, int cus) {
-  const unsigned grid = (unsigned)std::min<size_t>(count, (size_t)(cus > 0 ? cus : 1));
+  const size_t per_group = N >= 8192 ? 1 : 8192 / N;      // ciphertexts per workgroup (Geo::CPW)
+  const unsigned grid = (unsigned)std::min<size_t>((count + per_group - 1) / per_group, (size_t)(cus > 0 ? cus : 1));
   if (grid_out) *grid_out = grid;
-  return (size_t)grid * 2 * N * sizeof(uint32_t);
+  return (size_t)grid * per_group * 2 * N * sizeof(uint32_t);
 }
 
 void wave16k_fill_tables(uint32_t N, double2* t) {
@@ -638,15 +688,17 @@ void wave16k_fill_tables(uint32_t N, double2* t) {
 
 template <typename T>
 int wave16k_bsk_to_fourier(const T* bsk_std, double2* fbsk, const double2* tables, uint32_t N, size_t polys, hipStream_t stream) {
-  if (N == 16384) {
-    auto kern = w16::bsk_fourier_kernel<T, 14>;
-    CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::lds_bytes<14>()));
-    hipLaunchKernelGGL(kern, dim3((unsigned)polys), dim3(w16::THREADS), w16::lds_bytes<14>(), stream, bsk_std, fbsk, tables, polys);
-  } else {
-    auto kern = w16::bsk_fourier_kernel<T, 13>;
-    CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w16::lds_bytes<13>()));
-    hipLaunchKernelGGL(kern, dim3((unsigned)polys), dim3(w16::THREADS), w16::lds_bytes<13>(), stream, bsk_std, fbsk, tables, polys);
-  }
+  auto run = [&](auto kern, size_t lds) -> int {
+    CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)polys), dim3(w16::THREADS), lds, stream, bsk_std, fbsk, tables, polys);
+    return CAMD_OK;
+  };
+  int rc = CAMD_EINVAL;
+  if (N == 16384) rc = run(w16::bsk_fourier_kernel<T, 14>, w16::lds_bytes<14>());
+  if (N == 8192) rc = run(w16::bsk_fourier_kernel<T, 13>, w16::lds_bytes<13>());
+  if (N == 4096) rc = run(w16::bsk_fourier_kernel<T, 12>, w16::lds_bytes<12>());
+  if (N == 2048) rc = run(w16::bsk_fourier_kernel<T, 11>, w16::lds_bytes<11>());
+  if (rc != CAMD_OK) return rc;
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;
 }
@@ -667,7 +719,7 @@ template <typename T>
 int wave16k_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
   if constexpr (sizeof(T) == 8) {
     if (a.count == 0) return CAMD_OK;
-    if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel (N >= 8192): the accumulator slabs were not reserved");
+    if (!a.scratch) return fail(CAMD_EINVAL, "wave kernel (N >= 2048): the accumulator slabs were not reserved");
     int dev = 0, cus = 0;
     CAMD_HIP(hipGetDevice(&dev));
     CAMD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -677,8 +729,11 @@ int wave16k_launch_pbs(const PbsLaunch<T>& a, hipStream_t stream) {
     if (a.k == 1 && a.N == 16384 && a.level == 3 && a.base_log == 11) return launch_instance16k<T, 14, 3, 11>(a, grid, stream);
     if (a.k == 1 && a.N == 8192 && a.level == 2 && a.base_log == 15) return launch_instance16k<T, 13, 2, 15>(a, grid, stream);
     if (a.k == 1 && a.N == 8192 && a.level == 1 && a.base_log == 23) return launch_instance16k<T, 13, 1, 23>(a, grid, stream);
+    if (a.k == 1 && a.N == 4096 && a.level == 2 && a.base_log == 15) return launch_instance16k<T, 12, 2, 15>(a, grid, stream);
+    if (a.k == 1 && a.N == 4096 && a.level == 1 && a.base_log == 23) return launch_instance16k<T, 12, 1, 23>(a, grid, stream);
+    if (a.k == 1 && a.N == 2048 && a.level == 1 && a.base_log == 23) return launch_instance16k<T, 11, 1, 23>(a, grid, stream);
   }
-  return fail(CAMD_EINVAL, "wave kernel (N >= 8192): no instance for this parameter set");
+  return fail(CAMD_EINVAL, "wave kernel (N >= 2048): no instance for this parameter set");
 }
 
 template int wave16k_bsk_to_fourier<uint64_t>(const uint64_t*, double2*, const double2*, uint32_t, size_t, hipStream_t);
