@@ -61,13 +61,13 @@ typedef struct camd_params {
  * the CPU restatement of the reference algorithm; WAVE (the fastest where it has an instance)
  * performs the same algorithm with its own order of f64 operations: decryptions and the noise
  * bound are the same, the last bits of a ciphertext may differ. AUTO picks WAVE wherever it has an
- * instance (shortint: N = 1024 with k = 2, N = 512 with k = 3, N = 16384 and N = 8192 with k = 1 and
- * two levels of base 2^15, N = 8192 with k = 1 and one level of base 2^23; the two boolean parameter
+ * instance (shortint: N = 1024 with k = 2, N = 512 with k = 3, N = 4096 ... 16384 with k = 1 and
+ * two levels of base 2^15, N = 2048 ... 8192 with k = 1 and one level of base 2^23; the two boolean parameter
  * sets, 32-bit torus: N = 512, k = 2, two levels; N = 1024, k = 1, three levels) and BLOCK otherwise.
  * (N = 16384 with three levels of base 2^11 has a WAVE instance that AUTO does not select: the 32-bit
  * accumulator would be most of that set's small output noise.)
  * The shortint instances keep 32 bits per accumulator coefficient (N = 1024 and N = 512: in large
- * batches; N >= 8192: always): the ciphertexts they return have zero low dwords, and each
+ * batches; N >= 2048: always): the ciphertexts they return have zero low dwords, and each
  * blind-rotation step is rounded at 2^-32 of the torus (far below the output noise; part of the
  * tested bound).
  * A WAVE batch of at most one ciphertext per CU (two for N = 512) runs on a variant that gives
