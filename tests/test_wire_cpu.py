@@ -181,6 +181,29 @@ def test_fourier_payload_of_another_build_is_refused():
         wire.parse_fourier_key_payload(payload(wire.FOURIER_FORMAT, 9, ids[2]), p, 64)
 
 
+def test_kernel_family_that_auto_selects_for_every_parameter_set():
+    """CAMD_PBS_AUTO resolves (on the host, no GPU) to the wave family for every shortint set of the
+    reference except the three N = 256 sets and the three-level 1_7, and for both boolean sets; the
+    layout id of AUTO then equals the wave family's and differs from the block family's.
+    Parameter sets: concrete-shortint/src/parameters/mod.rs:179-808, concrete-boolean/src/parameters/mod.rs:30-72."""
+    from concrete_amd.backend import CAMD_PBS_AUTO, CAMD_PBS_BLOCK, CAMD_PBS_WAVE, fourier_layout_id
+
+    block_sets = {"PARAM_MESSAGE_1_CARRY_0", "PARAM_MESSAGE_1_CARRY_1", "PARAM_MESSAGE_2_CARRY_0", "PARAM_MESSAGE_1_CARRY_7"}
+    seen = 0
+    for name, p in sorted(P.SHORTINT_BY_NAME.items()):
+        auto, block = fourier_layout_id(p, CAMD_PBS_AUTO, 64), fourier_layout_id(p, CAMD_PBS_BLOCK, 64)
+        if name in block_sets:
+            assert auto == block, name
+        else:
+            assert auto == fourier_layout_id(p, CAMD_PBS_WAVE, 64) != block, name
+        seen += 1
+    assert seen >= 30
+    # the three-level set has a wave instance, on request only
+    assert fourier_layout_id(P.PARAM_MESSAGE_1_CARRY_7, CAMD_PBS_WAVE, 64) != fourier_layout_id(P.PARAM_MESSAGE_1_CARRY_7, CAMD_PBS_BLOCK, 64)
+    for p in (P.DEFAULT_PARAMETERS, P.TFHE_LIB_PARAMETERS):
+        assert fourier_layout_id(p, CAMD_PBS_AUTO, 32) == fourier_layout_id(p, CAMD_PBS_WAVE, 32)
+
+
 def test_param_names():
     assert keycache.param_name(P.PARAM_MESSAGE_2_CARRY_2) == "PARAM_MESSAGE_2_CARRY_2"
     assert keycache.FileStorage("some/dir").path(P.PARAM_MESSAGE_4_CARRY_4) == "some/dir/PARAM_MESSAGE_4_CARRY_4.bin"
