@@ -1,4 +1,5 @@
-"""Throughput probe: KS+PBS batch on device-resident random inputs (timing is data-independent)."""
+"""Throughput probe: KS+PBS batch on device-resident random inputs (timing is data-independent).
+QB_PARAMS names the parameter set (default PARAM_MESSAGE_2_CARRY_2)."""
 import sys, os, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import concrete_amd.parameters as P
@@ -6,7 +7,7 @@ from concrete_amd.backend import Context, DeviceServerKey
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-p = P.PARAM_MESSAGE_2_CARRY_2
+p = getattr(P, os.environ.get('QB_PARAMS', 'PARAM_MESSAGE_2_CARRY_2'))
 n, k, N = p.lwe_dimension, p.glwe_dimension, p.polynomial_size
 rs = np.random.RandomState(0)
 bsk = rs.randint(0, 2**63, size=(n, p.pbs_level, k + 1, k + 1, N), dtype=np.uint64) * np.uint64(2)
