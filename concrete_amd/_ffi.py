@@ -66,6 +66,8 @@ SYMBOLS = {
     "camd_ks_batch_device": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "camd_lwe_axpby_device": (_i, [_vp, C.c_uint32, _vp, _sz, _vp, _sz, C.c_uint64, _vp, _sz, C.c_uint64, C.c_uint64, _sz,
                                    _sz, _vp]),
+    "camd_axpby_ks_pbs_batch_device": (_i, [_vp, _vp, _sz, C.c_uint64, _vp, _sz, C.c_uint64, C.c_uint64, _vp, _vp, _sz, _vp]),
+    "camd_axpby_pbs_ks_batch_device": (_i, [_vp, _vp, _sz, C.c_uint64, _vp, _sz, C.c_uint64, C.c_uint64, _vp, _vp, _sz, _vp]),
     "camd_measure_fp64_fma_rate": (_i, [_vp, C.POINTER(C.c_double)]),
     "camd_timing_enable": (_i, [_vp, _i]),
     "camd_timing_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),

@@ -247,6 +247,32 @@ class DeviceServerKey:
     def pbs_device(self, ct_in, lut_ids, ct_out, count: int, stream: int = 0) -> None:
         self._dev(_ffi.lib().camd_pbs_batch_device, ct_in, lut_ids, ct_out, count, stream)
 
+    def _combined(self, fn, words, x, alpha, y, beta, body_add, lut_ids, ct_out, stream):
+        for t in (x,) + ((y,) if y is not None else ()):
+            if t.dim() != 2 or t.stride(1) != 1 or t.shape[1] != words or t.shape[0] != x.shape[0]:
+                raise ValueError("combined batch: operands must be [count][words] tensors with contiguous rows")
+        if ct_out.dim() != 2 or not ct_out.is_contiguous() or ct_out.shape != (x.shape[0], words):
+            raise ValueError("combined batch: the output must be a contiguous [count][words] tensor")
+        mask = (1 << 64) - 1
+        count = x.shape[0]
+        self.launches += 1
+        self.bootstraps += int(count)
+        check(fn(self._h, C.c_void_p(x.data_ptr()), x.stride(0), int(alpha) & mask,
+                 C.c_void_p(y.data_ptr()) if y is not None else None, y.stride(0) if y is not None else 0, int(beta) & mask,
+                 int(body_add) & mask, C.c_void_p(lut_ids.data_ptr()) if lut_ids is not None else None,
+                 C.c_void_p(ct_out.data_ptr()), int(count), C.c_void_p(stream)))
+
+    def axpby_ks_pbs_device(self, x, alpha: int, y, beta: int, body_add: int, lut_ids, ct_out, stream: int = 0) -> None:
+        """ks_pbs_device on the rows alpha*x + beta*y (+ body_add on the body), formed by the keyswitch
+        while it reads; ``x`` and ``y`` (or None) may be row-strided views."""
+        self._combined(_ffi.lib().camd_axpby_ks_pbs_batch_device, self.big + 1, x, alpha, y, beta, body_add, lut_ids, ct_out,
+                       stream)
+
+    def axpby_pbs_ks_device(self, x, alpha: int, y, beta: int, body_add: int, lut_ids, ct_out, stream: int = 0) -> None:
+        """pbs_ks_device on the rows alpha*x + beta*y (+ body_add on the body)."""
+        self._combined(_ffi.lib().camd_axpby_pbs_ks_batch_device, self.n + 1, x, alpha, y, beta, body_add, lut_ids, ct_out,
+                       stream)
+
     def ks_device(self, ct_in, ct_out, count: int, stream: int = 0) -> None:
         self._dev(_ffi.lib().camd_ks_batch_device, ct_in, None, ct_out, count, stream, with_ids=False)
 

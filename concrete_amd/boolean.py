@@ -229,8 +229,8 @@ class ServerKey:
 
     def gate_batch(self, gate: str, a, b):
         """One gate on many ciphertext pairs. Host arrays ([count][n+1] uint32) go through the host
-        entry point; torch CUDA int32 tensors stay on the GPU: the gate's linear combination is one
-        ``camd_lwe_axpby_device`` pass and the bootstrap + keyswitch reads its output in place."""
+        entry point; torch CUDA int32 tensors stay on the GPU, where the gate is one call
+        (``camd_axpby_pbs_ks_batch_device``: linear combination, bootstrap, keyswitch)."""
         if isinstance(a, np.ndarray):
             a = np.ascontiguousarray(a, dtype=np.uint32)
             b = np.ascontiguousarray(b, dtype=np.uint32)
@@ -240,8 +240,6 @@ class ServerKey:
         alpha, beta, plain = self._LINEAR[gate]
         key = self.bootstrapper.key
         stream = torch.cuda.current_stream().cuda_stream
-        mixed = torch.empty_like(a)
-        key.ctx.lwe_axpby_device(mixed, a, alpha, b, beta, plain, 32, stream)
-        out = torch.empty_like(a)
-        key.pbs_ks_device(mixed, None, out, a.shape[0], stream)
+        out = torch.empty((a.shape[0], a.shape[1]), dtype=a.dtype, device=a.device)
+        key.axpby_pbs_ks_device(a, alpha, b, beta, plain, None, out, stream)
         return out

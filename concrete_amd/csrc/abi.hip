@@ -81,6 +81,15 @@ struct Timing {
 
 enum class Op { KsPbs, PbsKs, Pbs, Ks };
 
+// A linear combination formed ahead of the first kernel of an operation: that kernel's input rows
+// are alpha * x + beta * y, body_add added to the body (kernels.hpp: LweInput). Strides in words.
+struct Combination {
+  size_t x_stride;
+  const void* y;
+  size_t y_stride;
+  uint64_t alpha, beta, body_add;
+};
+
 // One blocked caller of a host-pointer entry point.
 struct HostRequest {
   Op op;
@@ -109,6 +118,7 @@ struct camd_server_key {
   uint32_t lut_count = 0;
   // scratch
   DeviceBuffer mid;         // keyswitch output (shortint order) or bootstrap output (boolean order)
+  DeviceBuffer lin;         // a combination written out, for the bootstrap kernels that read plain batches only
   DeviceBuffer pbs_scratch;
   DeviceBuffer ks_limbs;    // keyswitch key as balanced byte limbs (matrix-core keyswitch), derived from the blob
   DeviceBuffer ks_digits;   // digits of a batch (matrix-core keyswitch)
@@ -307,6 +317,7 @@ void key_free(camd_server_key* key) {
   if (key->device_done) (void)hipEventDestroy(key->device_done);
   key->luts.release();
   key->mid.release();
+  key->lin.release();
   key->pbs_scratch.release();
   key->ks_limbs.release();
   key->ks_digits.release();
@@ -360,12 +371,37 @@ struct TimedRegion {
 };
 
 template <typename T>
-int run_pbs(camd_server_key* key, const T* in, size_t in_stride, const uint32_t* ids, T* out, size_t out_stride,
+LweInput<T> input_of(const void* x, size_t dense_stride, uint32_t dimension, const Combination* c) {
+  if (!c) return LweInput<T>::plain((const T*)x, dense_stride, dimension);
+  return LweInput<T>{(const T*)x, c->x_stride, (const T*)c->y, c->y_stride, (T)c->alpha, (T)c->beta, (T)c->body_add, dimension};
+}
+
+// The bootstrap kernels that form an LweInput while they read (kernels.hpp: input_row): the
+// workgroup-per-ciphertext families. For the wave family run_pbs writes the combination out first:
+// its kernels fetch the next mask element as one scalar a whole iteration ahead, and forming it
+// from two operands inside that loop cost the N = 512 instances 4 % (32-bit, two levels) to 39 %
+// (64-bit, one level) of their time, against 0.05 % for the pass that writes (n + 1) words per
+// ciphertext.
+bool pbs_family_combines(const camd_server_key* key) { return key->variant != CAMD_PBS_WAVE; }
+
+template <typename T>
+int run_pbs(camd_server_key* key, LweInput<T> in, const uint32_t* ids, T* out, size_t out_stride,
             size_t count, hipStream_t s, void* scratch_override = nullptr) {
   if (key->lut_count == 0) return fail(CAMD_EINVAL, "no look-up table uploaded for this key");
   const camd_params& p = key->p;
+  if (!in.is_plain() && !pbs_family_combines(key)) {
+    if (scratch_override) return fail(CAMD_EINVAL, "internal: a combination on the path that allocates nothing");
+    const size_t words = (size_t)p.lwe_dimension + 1;
+    int rc = key->lin.ensure(count * words * sizeof(T));
+    if (rc != CAMD_OK) return rc;
+    rc = launch_lwe_axpby<T>((T*)key->lin.ptr, words, in.x, in.x_stride, in.alpha, in.y, in.y_stride, in.beta, in.body_add,
+                             words, count, s);
+    if (rc != CAMD_OK) return rc;
+    in = LweInput<T>::plain((const T*)key->lin.ptr, words, p.lwe_dimension);
+  }
   PbsLaunch<T> a{};
-  a.ct_in = in; a.in_stride = in_stride; a.ct_out = out; a.out_stride = out_stride;
+  a.ct_in = in.x; a.in_stride = in.x_stride; a.ct_out = out; a.out_stride = out_stride;
+  a.y_in = in.y; a.y_stride = in.y_stride; a.alpha = in.alpha; a.beta = in.beta; a.body_add = in.body_add;
   a.lut_ids = ids; a.luts = (const T*)key->luts.ptr; a.lut_count = key->lut_count; a.count = count;
   a.fbsk = key->fbsk(); a.tables = key->tables; a.status = key->status;
   a.scratch = scratch_override ? scratch_override : key->pbs_scratch.ptr;
@@ -382,17 +418,17 @@ int run_pbs(camd_server_key* key, const T* in, size_t in_stride, const uint32_t*
 }
 
 template <typename T>
-int run_ks(camd_server_key* key, const T* in, size_t in_stride, T* out, size_t out_stride, size_t count, hipStream_t s,
+int run_ks(camd_server_key* key, const LweInput<T>& in, T* out, size_t out_stride, size_t count, hipStream_t s,
            bool timed = true) {
   const camd_params& p = key->p;
   if (!timed)   // the entry point that allocates nothing: the kernel that needs no digit scratch
-    return launch_keyswitch<T>(in, in_stride, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
+    return launch_keyswitch<T>(in, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
                                p.ks_base_log, p.ks_level, count, s);
   TimedRegion t(key, false, s);
   if (ks_use_mfma(key, count) && key->ks_digits.bytes >= keyswitch_mfma_digit_bytes((uint32_t)key->big(), p.ks_level, count))
-    return launch_keyswitch_mfma<T>(in, in_stride, out, out_stride, (const int8_t*)key->ks_limbs.ptr, (int8_t*)key->ks_digits.ptr,
+    return launch_keyswitch_mfma<T>(in, out, out_stride, (const int8_t*)key->ks_limbs.ptr, (int8_t*)key->ks_digits.ptr,
                                     (uint32_t)key->big(), p.lwe_dimension, p.ks_base_log, p.ks_level, count, s);
-  return launch_keyswitch<T>(in, in_stride, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
+  return launch_keyswitch<T>(in, out, out_stride, (const T*)key->ksk(), (uint32_t)key->big(), p.lwe_dimension,
                              p.ks_base_log, p.ks_level, count, s);
 }
 
@@ -404,24 +440,28 @@ size_t out_words(const camd_server_key* k, Op op) {
 }
 
 template <typename T>
-int run_op_device(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count, hipStream_t s) {
+int run_op_device(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count, hipStream_t s,
+                  const Combination* comb = nullptr) {
   int rc = reserve_locked(key, count);
   if (rc != CAMD_OK) return rc;
-  const size_t big1 = key->big() + 1, small1 = (size_t)key->p.lwe_dimension + 1;
+  const uint32_t big = (uint32_t)key->big(), small = key->p.lwe_dimension;
+  const size_t big1 = (size_t)big + 1, small1 = (size_t)small + 1;
+  const LweInput<T> mid_small = LweInput<T>::plain((const T*)key->mid.ptr, small1, small);
+  const LweInput<T> mid_big = LweInput<T>::plain((const T*)key->mid.ptr, big1, big);
   switch (op) {
     case Op::KsPbs:
-      rc = run_ks<T>(key, (const T*)in, big1, (T*)key->mid.ptr, small1, count, s);
-      if (rc == CAMD_OK) rc = run_pbs<T>(key, (const T*)key->mid.ptr, small1, ids, (T*)out, big1, count, s);
+      rc = run_ks<T>(key, input_of<T>(in, big1, big, comb), (T*)key->mid.ptr, small1, count, s);
+      if (rc == CAMD_OK) rc = run_pbs<T>(key, mid_small, ids, (T*)out, big1, count, s);
       break;
     case Op::PbsKs:
-      rc = run_pbs<T>(key, (const T*)in, small1, ids, (T*)key->mid.ptr, big1, count, s);
-      if (rc == CAMD_OK) rc = run_ks<T>(key, (const T*)key->mid.ptr, big1, (T*)out, small1, count, s);
+      rc = run_pbs<T>(key, input_of<T>(in, small1, small, comb), ids, (T*)key->mid.ptr, big1, count, s);
+      if (rc == CAMD_OK) rc = run_ks<T>(key, mid_big, (T*)out, small1, count, s);
       break;
     case Op::Pbs:
-      rc = run_pbs<T>(key, (const T*)in, small1, ids, (T*)out, big1, count, s);
+      rc = run_pbs<T>(key, input_of<T>(in, small1, small, comb), ids, (T*)out, big1, count, s);
       break;
     case Op::Ks:
-      rc = run_ks<T>(key, (const T*)in, big1, (T*)out, small1, count, s);
+      rc = run_ks<T>(key, input_of<T>(in, big1, big, comb), (T*)out, small1, count, s);
       break;
   }
   return rc;
@@ -444,8 +484,13 @@ int order_after_device_calls(camd_server_key* key, hipStream_t s) {
   return CAMD_OK;
 }
 
-int dispatch_device(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count, void* stream) {
+int dispatch_device(camd_server_key* key, Op op, const void* in, const uint32_t* ids, void* out, size_t count, void* stream,
+                    const Combination* comb = nullptr) {
   if (!key || (!in && count) || (!out && count)) return fail(CAMD_EINVAL, "null argument");
+  if (comb && count) {
+    const size_t words = in_words(key, op);
+    if (comb->x_stride < words || (comb->y && comb->y_stride < words)) return fail(CAMD_EINVAL, "row stride shorter than the ciphertext");
+  }
   std::lock_guard<std::mutex> lock(key->mu);
   int rc = report_status(key);
   if (rc != CAMD_OK) return rc;
@@ -455,8 +500,8 @@ int dispatch_device(camd_server_key* key, Op op, const void* in, const uint32_t*
   hipStream_t s = (hipStream_t)stream;
   rc = order_after_device_calls(key, s);
   if (rc != CAMD_OK) return rc;
-  rc = key->p.torus_bits == 64 ? run_op_device<uint64_t>(key, op, in, ids, out, count, s)
-                               : run_op_device<uint32_t>(key, op, in, ids, out, count, s);
+  rc = key->p.torus_bits == 64 ? run_op_device<uint64_t>(key, op, in, ids, out, count, s, comb)
+                               : run_op_device<uint32_t>(key, op, in, ids, out, count, s, comb);
   // recorded even after a failed launch sequence: whatever was enqueued must be waited for
   CAMD_HIP(hipEventRecord(key->device_done, s));
   key->device_stream = s;
@@ -945,7 +990,8 @@ int camd_ks_pbs_batch_device_noalloc(camd_server_key* key, const void* ct_in, co
   if (key->variant != CAMD_PBS_WAVE || !wave_scratch_is_fixed(key->p))
     return fail(CAMD_EINVAL, "the no-allocation entry point serves keys of the wave kernel family with N <= 1024 only (the "
                              "other kernels need per-ciphertext scratch that grows with the batch)");
-  const size_t small1 = (size_t)key->p.lwe_dimension + 1, big1 = key->big() + 1;
+  const uint32_t small = key->p.lwe_dimension, big = (uint32_t)key->big();
+  const size_t small1 = (size_t)small + 1, big1 = (size_t)big + 1;
   const size_t max_count = NOALLOC_MID_BYTES / (small1 * key->word);
   if (count > max_count)
     return fail(CAMD_EINVAL, "batch too large for the no-allocation entry point: its fixed scratch holds the keyswitch "
@@ -968,11 +1014,15 @@ int camd_ks_pbs_batch_device_noalloc(camd_server_key* key, const void* ct_in, co
   void* counters = base;
   void* mid = base + NOALLOC_COUNTER_BYTES;
   if (key->p.torus_bits == 64) {
-    rc = run_ks<uint64_t>(key, (const uint64_t*)ct_in, big1, (uint64_t*)mid, small1, count, s, false);
-    if (rc == CAMD_OK) rc = run_pbs<uint64_t>(key, (const uint64_t*)mid, small1, lut_ids, (uint64_t*)ct_out, big1, count, s, counters);
+    rc = run_ks<uint64_t>(key, LweInput<uint64_t>::plain((const uint64_t*)ct_in, big1, big), (uint64_t*)mid, small1, count, s, false);
+    if (rc == CAMD_OK)
+      rc = run_pbs<uint64_t>(key, LweInput<uint64_t>::plain((const uint64_t*)mid, small1, small), lut_ids, (uint64_t*)ct_out, big1,
+                             count, s, counters);
   } else {
-    rc = run_ks<uint32_t>(key, (const uint32_t*)ct_in, big1, (uint32_t*)mid, small1, count, s, false);
-    if (rc == CAMD_OK) rc = run_pbs<uint32_t>(key, (const uint32_t*)mid, small1, lut_ids, (uint32_t*)ct_out, big1, count, s, counters);
+    rc = run_ks<uint32_t>(key, LweInput<uint32_t>::plain((const uint32_t*)ct_in, big1, big), (uint32_t*)mid, small1, count, s, false);
+    if (rc == CAMD_OK)
+      rc = run_pbs<uint32_t>(key, LweInput<uint32_t>::plain((const uint32_t*)mid, small1, small), lut_ids, (uint32_t*)ct_out, big1,
+                             count, s, counters);
   }
   CAMD_HIP(hipEventRecord(key->device_done, s));
   key->device_stream = s;
@@ -989,6 +1039,19 @@ int camd_pbs_batch_device(camd_server_key* key, const void* ct_in, const uint32_
 }
 int camd_ks_batch_device(camd_server_key* key, const void* ct_in, void* ct_out, size_t count, void* stream) {
   return dispatch_device(key, Op::Ks, ct_in, nullptr, ct_out, count, stream);
+}
+
+int camd_axpby_ks_pbs_batch_device(camd_server_key* key, const void* x, size_t x_stride, uint64_t alpha, const void* y,
+                                   size_t y_stride, uint64_t beta, uint64_t body_add, const uint32_t* lut_ids, void* ct_out,
+                                   size_t count, void* stream) {
+  const Combination c{x_stride, y, y_stride, alpha, beta, body_add};
+  return dispatch_device(key, Op::KsPbs, x, lut_ids, ct_out, count, stream, &c);
+}
+int camd_axpby_pbs_ks_batch_device(camd_server_key* key, const void* x, size_t x_stride, uint64_t alpha, const void* y,
+                                   size_t y_stride, uint64_t beta, uint64_t body_add, const uint32_t* lut_ids, void* ct_out,
+                                   size_t count, void* stream) {
+  const Combination c{x_stride, y, y_stride, alpha, beta, body_add};
+  return dispatch_device(key, Op::PbsKs, x, lut_ids, ct_out, count, stream, &c);
 }
 
 int camd_lwe_axpby_device(camd_context* ctx, uint32_t torus_bits, void* out, size_t out_stride, const void* x,

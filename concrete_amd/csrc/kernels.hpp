@@ -7,11 +7,61 @@
 
 namespace camd {
 
+// The input ciphertexts of a keyswitch or a bootstrap, as a linear combination that the kernel
+// forms while it reads: row c is alpha * x[c] + beta * y[c] (wrapping), with body_add added to its
+// last word (index `body`). A plain batch is alpha = 1, y = nullptr, body_add = 0. This is how the
+// leveled operations the reference performs ahead of a bootstrap (the shift-and-add of
+// concrete-shortint/src/engine/server_side/mod.rs:182-188, the gate combinations of
+// concrete-boolean/src/engine/mod.rs:347-353) ride on the first kernel's loads.
+template <typename T>
+struct LweInput {
+  const T* x;
+  size_t x_stride;
+  const T* y;                // nullptr: no second operand
+  size_t y_stride;
+  T alpha, beta, body_add;
+  uint32_t body;             // index of the body word = the dimension of the input ciphertexts
+  static LweInput plain(const T* x, size_t stride, uint32_t dimension) {
+    return LweInput{x, stride, nullptr, 0, T(1), T(0), T(0), dimension};
+  }
+  bool is_plain() const { return y == nullptr && alpha == T(1) && body_add == T(0); }
+  __device__ __forceinline__ T at(size_t c, uint32_t j) const {
+    T v = alpha * x[c * x_stride + j];
+    if (y) v += beta * y[c * y_stride + j];
+    return j == body ? (T)(v + body_add) : v;
+  }
+  LweInput rows_from(size_t first) const {
+    LweInput r = *this;
+    r.x += first * x_stride;
+    if (r.y) r.y += first * y_stride;
+    return r;
+  }
+};
+
+// One row of an LweInput, indexed like the array it stands for.
+template <typename T>
+struct LweInputRow {
+  const T* x;
+  const T* y;
+  T alpha, beta, body_add;
+  uint32_t body;
+  __device__ __forceinline__ T operator[](uint32_t j) const {
+    T v = alpha * x[j];
+    if (y) v += beta * y[j];
+    return j == body ? (T)(v + body_add) : v;
+  }
+};
+
 // Everything a bootstrap launch needs. Pointers are device memory.
 template <typename T>
 struct PbsLaunch {
   const T* ct_in;            // [count][in_stride], n+1 words used
   size_t in_stride;
+  // Second operand and coefficients of an LweInput whose x is ct_in. Only the generic and block
+  // families look at these (through input_row); the wave family is handed plain batches.
+  const T* y_in;
+  size_t y_stride;
+  T alpha, beta, body_add;
   T* ct_out;                 // [count][out_stride], kN+1 words written
   size_t out_stride;
   const uint32_t* lut_ids;   // [count] or nullptr (lut 0)
@@ -26,6 +76,12 @@ struct PbsLaunch {
 };
 
 constexpr uint32_t STATUS_BAD_LUT_ID = 1u;
+
+template <typename T>
+__device__ __forceinline__ LweInputRow<T> input_row(const PbsLaunch<T>& a, size_t ct) {
+  return LweInputRow<T>{a.ct_in + ct * a.in_stride, a.y_in ? a.y_in + ct * a.y_stride : nullptr, a.alpha, a.beta,
+                        a.body_add, a.n};
+}
 
 // Look-up table of ciphertext `ct`. The host-pointer entry points reject an id that is out of range
 // before anything is launched; a device-pointer call cannot look at its ids without a round trip,
@@ -88,7 +144,7 @@ struct XcdRendezvous {
 };
 // ---- keyswitch (keyswitch.hip) ----
 template <typename T>
-int launch_keyswitch(const T* ct_in, size_t in_stride, T* ct_out, size_t out_stride, const T* ksk,
+int launch_keyswitch(const LweInput<T>& in, T* ct_out, size_t out_stride, const T* ksk,
                      uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level, size_t count,
                      hipStream_t stream);
 
@@ -101,7 +157,7 @@ size_t keyswitch_mfma_digit_bytes(uint32_t in_dim, uint32_t level, size_t count)
 template <typename T>
 int keyswitch_mfma_prepare(const T* ksk, int8_t* limbs, uint32_t in_dim, uint32_t out_dim, uint32_t level, hipStream_t stream);
 template <typename T>
-int launch_keyswitch_mfma(const T* ct_in, size_t in_stride, T* ct_out, size_t out_stride, const int8_t* limbs,
+int launch_keyswitch_mfma(const LweInput<T>& in, T* ct_out, size_t out_stride, const int8_t* limbs,
                           int8_t* digits, uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level, size_t count,
                           hipStream_t stream);
 

@@ -70,7 +70,7 @@ __device__ __forceinline__ uint64_t exact_to_u64(double v) {
 
 template <typename T>
 __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void keyswitch_kernel(
-    const T* __restrict__ ct_in, size_t in_stride, T* __restrict__ ct_out, size_t out_stride,
+    const LweInput<T> in, T* __restrict__ ct_out, size_t out_stride,
     const T* __restrict__ ksk, uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level,
     size_t count, uint32_t flush_chunks, uint32_t chunks_per_split) {
   constexpr int LIMBS = sizeof(T) / 4;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
       const uint32_t c = e % KS_CT_TILE, ii = e / KS_CT_TILE;
       const uint32_t i = i0 + ii;
       T a = 0;
-      if (ct0 + c < count) a = ct_in[(ct0 + c) * in_stride + i];
+      if (ct0 + c < count) a = in.at(ct0 + c, i);
       T state = decomp_init_state<T>(a, base_log, level);
       for (uint32_t l = level; l >= 1; l--)
         digits[(ii * level + (l - 1)) * KS_CT_TILE + c] = (double)(int32_t)decomp_next<T>(state, base_log);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
           if constexpr (sizeof(T) == 8) atomicAdd((unsigned long long*)dst, (unsigned long long)v);
           else atomicAdd((unsigned int*)dst, (unsigned int)v);
         } else {
-          if (col == out_dim) v += ct_in[(ct0 + c) * in_stride + in_dim];
+          if (col == out_dim) v += in.at(ct0 + c, in_dim);
           *dst = v;
         }
       }
@@ -201,22 +201,23 @@ __global__ __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 
 // out = (0, ..., 0, b_in): the start value of a keyswitch whose key rows are split over blocks
 template <typename T>
-__global__ __launch_bounds__(256) void keyswitch_preset_kernel(const T* __restrict__ ct_in, size_t in_stride,
+__global__ __launch_bounds__(256) void keyswitch_preset_kernel(const LweInput<T> in,
                                                                T* __restrict__ ct_out, size_t out_stride,
                                                                uint32_t in_dim, uint32_t out_dim, size_t count) {
   const uint32_t col = blockIdx.x * 256 + threadIdx.x;
   const size_t c = blockIdx.y;
   if (col > out_dim || c >= count) return;
-  ct_out[c * out_stride + col] = (col == out_dim) ? ct_in[c * in_stride + in_dim] : T(0);
+  ct_out[c * out_stride + col] = (col == out_dim) ? in.at(c, in_dim) : T(0);
 }
 
 }  // namespace
 
 template <typename T>
-int launch_keyswitch(const T* ct_in, size_t in_stride, T* ct_out, size_t out_stride, const T* ksk,
+int launch_keyswitch(const LweInput<T>& in, T* ct_out, size_t out_stride, const T* ksk,
                      uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level, size_t count,
                      hipStream_t stream) {
   if (count == 0) return CAMD_OK;
+  if (in.body != in_dim) return fail(CAMD_EINVAL, "keyswitch: the input's body index is not the input dimension");
   if (level > KS_MAX_LEVEL) return fail(CAMD_EINVAL, "keyswitch: level count above 8 is not supported");
   if (in_dim == 0 || in_dim % KS_CHUNK != 0)
     return fail(CAMD_EINVAL, "keyswitch: input dimension must be a positive multiple of 32");
@@ -242,20 +243,20 @@ int launch_keyswitch(const T* ct_in, size_t in_stride, T* ct_out, size_t out_str
   if (splits > 1) {
     if (count > 65535) return fail(CAMD_EINVAL, "keyswitch: internal split of a large batch");  // cannot happen: blocks < KS_FILL
     hipLaunchKernelGGL(keyswitch_preset_kernel<T>, dim3((ncols + 255) / 256, (unsigned)count), dim3(256), 0, stream,
-                       ct_in, in_stride, ct_out, out_stride, in_dim, out_dim, count);
+                       in, ct_out, out_stride, in_dim, out_dim, count);
     CAMD_HIP(hipGetLastError());
   }
   grid.z = splits;
   const size_t lds = (size_t)KS_CHUNK * level * KS_CT_TILE * sizeof(double);
-  hipLaunchKernelGGL(keyswitch_kernel<T>, grid, dim3(KS_THREADS), lds, stream, ct_in, in_stride, ct_out,
+  hipLaunchKernelGGL(keyswitch_kernel<T>, grid, dim3(KS_THREADS), lds, stream, in, ct_out,
                      out_stride, ksk, in_dim, out_dim, base_log, level, count, flush_chunks, chunks_per_split);
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;
 }
 
-template int launch_keyswitch<uint64_t>(const uint64_t*, size_t, uint64_t*, size_t, const uint64_t*, uint32_t,
+template int launch_keyswitch<uint64_t>(const LweInput<uint64_t>&, uint64_t*, size_t, const uint64_t*, uint32_t,
                                         uint32_t, uint32_t, uint32_t, size_t, hipStream_t);
-template int launch_keyswitch<uint32_t>(const uint32_t*, size_t, uint32_t*, size_t, const uint32_t*, uint32_t,
+template int launch_keyswitch<uint32_t>(const LweInput<uint32_t>&, uint32_t*, size_t, const uint32_t*, uint32_t,
                                         uint32_t, uint32_t, uint32_t, size_t, hipStream_t);
 
 }  // namespace camd

@@ -80,33 +80,33 @@ __global__ __launch_bounds__(256) void ks_limbs_kernel(const T* __restrict__ ksk
 // thread = one mask element of one ciphertext: `level` bytes at kappa = i*level + (l-1), the row
 // order of the key (level 1 first); the decomposer yields the finest level first.
 template <typename T>
-__global__ __launch_bounds__(256) void ks_digits_kernel(const T* __restrict__ ct_in, size_t in_stride,
+__global__ __launch_bounds__(256) void ks_digits_kernel(const LweInput<T> in,
                                                         int8_t* __restrict__ digits, uint32_t in_dim, uint32_t base_log,
                                                         uint32_t level, size_t count) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   const size_t b = blockIdx.y;
   if (i >= in_dim || b >= count) return;
-  T state = decomp_init_state<T>(ct_in[b * in_stride + i], base_log, level);
+  T state = decomp_init_state<T>(in.at(b, i), base_log, level);
   int8_t* dst = digits + (b * in_dim + i) * level;
   for (uint32_t l = level; l >= 1; l--) dst[l - 1] = (int8_t)decomp_next<T>(state, base_log);
 }
 
 // out = (0, ..., 0, b_in): the start value when the partial sums arrive by atomics
 template <typename T>
-__global__ __launch_bounds__(256) void ksm_preset_kernel(const T* __restrict__ ct_in, size_t in_stride,
+__global__ __launch_bounds__(256) void ksm_preset_kernel(const LweInput<T> in,
                                                          T* __restrict__ ct_out, size_t out_stride, uint32_t in_dim,
                                                          uint32_t out_dim, size_t count) {
   const uint32_t col = blockIdx.x * 256 + threadIdx.x;
   const size_t c = blockIdx.y;
   if (col > out_dim || c >= count) return;
-  ct_out[c * out_stride + col] = (col == out_dim) ? ct_in[c * in_stride + in_dim] : T(0);
+  ct_out[c * out_stride + col] = (col == out_dim) ? in.at(c, in_dim) : T(0);
 }
 
 // ---- the contraction ----
 template <typename T>
 __global__ __launch_bounds__(KSM_THREADS, 1) void ks_mfma_kernel(const int8_t* __restrict__ digits,
                                                                  const int8_t* __restrict__ limbs,
-                                                                 const T* __restrict__ ct_in, size_t in_stride,
+                                                                 const LweInput<T> in,
                                                                  T* __restrict__ ct_out, size_t out_stride,
                                                                  uint32_t in_dim, uint32_t out_dim, uint32_t K, uint32_t npad,
                                                                  size_t count, uint32_t stages_per_split, int atomic) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(KSM_THREADS, 1) void ks_mfma_kernel(const int8_t* _
         if constexpr (sizeof(T) == 8) atomicAdd((unsigned long long*)dst, (unsigned long long)(T(0) - sum));
         else atomicAdd((unsigned int*)dst, (unsigned int)(T(0) - sum));
       } else {
-        const T base = (col == out_dim) ? ct_in[m * in_stride + in_dim] : T(0);
+        const T base = (col == out_dim) ? in.at(m, in_dim) : T(0);
         *dst = base - sum;
       }
     }
@@ -242,10 +242,11 @@ int keyswitch_mfma_prepare(const T* ksk, int8_t* limbs, uint32_t in_dim, uint32_
 }
 
 template <typename T>
-int launch_keyswitch_mfma(const T* ct_in, size_t in_stride, T* ct_out, size_t out_stride, const int8_t* limbs,
+int launch_keyswitch_mfma(const LweInput<T>& in, T* ct_out, size_t out_stride, const int8_t* limbs,
                           int8_t* digits, uint32_t in_dim, uint32_t out_dim, uint32_t base_log, uint32_t level, size_t count,
                           hipStream_t stream) {
   if (count == 0) return CAMD_OK;
+  if (in.body != in_dim) return fail(CAMD_EINVAL, "keyswitch: the input's body index is not the input dimension");
   if (!keyswitch_mfma_supported(in_dim, base_log, level)) return fail(CAMD_EINVAL, "keyswitch: no matrix-core form for this decomposition");
   if (count > 65535u * 16u) return fail(CAMD_EINVAL, "keyswitch: batch too large for one launch");
   const uint32_t K = in_dim * level, cols = out_dim + 1;
@@ -256,7 +257,7 @@ int launch_keyswitch_mfma(const T* ct_in, size_t in_stride, T* ct_out, size_t ou
     for (size_t first = 0; first < count; first += 65535) {
       const size_t nb = std::min<size_t>(65535, count - first);
       hipLaunchKernelGGL(ks_digits_kernel<T>, dim3((in_dim + 255) / 256, (unsigned)nb), dim3(256), 0, stream,
-                         ct_in + first * in_stride, in_stride, digits + first * (size_t)K, in_dim, base_log, level, nb);
+                         in.rows_from(first), digits + first * (size_t)K, in_dim, base_log, level, nb);
     }
     CAMD_HIP(hipGetLastError());
   }
@@ -276,7 +277,7 @@ int launch_keyswitch_mfma(const T* ct_in, size_t in_stride, T* ct_out, size_t ou
     for (size_t first = 0; first < count; first += 65535) {
       const size_t nb = std::min<size_t>(65535, count - first);
       hipLaunchKernelGGL(ksm_preset_kernel<T>, dim3((cols + 255) / 256, (unsigned)nb), dim3(256), 0, stream,
-                         ct_in + first * in_stride, in_stride, ct_out + first * out_stride, out_stride, in_dim, out_dim, nb);
+                         in.rows_from(first), ct_out + first * out_stride, out_stride, in_dim, out_dim, nb);
     }
     CAMD_HIP(hipGetLastError());
   }
@@ -284,7 +285,7 @@ int launch_keyswitch_mfma(const T* ct_in, size_t in_stride, T* ct_out, size_t ou
   static_assert(lds <= 160 * 1024, "LDS budget exceeded");
   auto kern = ks_mfma_kernel<T>;
   CAMD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(mt, nt, splits), dim3(KSM_THREADS), lds, stream, (const int8_t*)digits, limbs, ct_in, in_stride,
+  hipLaunchKernelGGL(kern, dim3(mt, nt, splits), dim3(KSM_THREADS), lds, stream, (const int8_t*)digits, limbs, in,
                      ct_out, out_stride, in_dim, out_dim, K, npad, count, per_split, splits > 1 ? 1 : 0);
   CAMD_HIP(hipGetLastError());
   return CAMD_OK;
@@ -292,9 +293,9 @@ int launch_keyswitch_mfma(const T* ct_in, size_t in_stride, T* ct_out, size_t ou
 
 template int keyswitch_mfma_prepare<uint64_t>(const uint64_t*, int8_t*, uint32_t, uint32_t, uint32_t, hipStream_t);
 template int keyswitch_mfma_prepare<uint32_t>(const uint32_t*, int8_t*, uint32_t, uint32_t, uint32_t, hipStream_t);
-template int launch_keyswitch_mfma<uint64_t>(const uint64_t*, size_t, uint64_t*, size_t, const int8_t*, int8_t*, uint32_t,
+template int launch_keyswitch_mfma<uint64_t>(const LweInput<uint64_t>&, uint64_t*, size_t, const int8_t*, int8_t*, uint32_t,
                                              uint32_t, uint32_t, uint32_t, size_t, hipStream_t);
-template int launch_keyswitch_mfma<uint32_t>(const uint32_t*, size_t, uint32_t*, size_t, const int8_t*, int8_t*, uint32_t,
+template int launch_keyswitch_mfma<uint32_t>(const LweInput<uint32_t>&, uint32_t*, size_t, const int8_t*, int8_t*, uint32_t,
                                              uint32_t, uint32_t, uint32_t, size_t, hipStream_t);
 
 }  // namespace camd

@@ -484,7 +484,7 @@ void block_pbs_kernel(PbsLaunch<T> a) {
   const bool pack16 = high_dword && L > 1 && bl * (L - 1u) + 1u <= 16u;
 
   for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
-    const T* in = a.ct_in + ct * a.in_stride;
+    const LweInputRow<T> in = input_row(a, ct);
     const uint32_t lut_id = checked_lut_id(a, ct);
     const T* lut = a.luts + (size_t)lut_id * G;
 

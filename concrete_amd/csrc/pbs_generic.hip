@@ -100,7 +100,7 @@ __global__ void generic_pbs_kernel(PbsLaunch<T> a) {
   const double inv_m = 1.0 / (double)M;
 
   for (size_t ct = blockIdx.x; ct < a.count; ct += gridDim.x) {
-    const T* in = a.ct_in + ct * a.in_stride;
+    const LweInputRow<T> in = input_row(a, ct);
     const uint32_t lut_id = checked_lut_id(a, ct);
     const T* lut = a.luts + (size_t)lut_id * G;
 

@@ -322,6 +322,28 @@ class ServerKey(ShortintOps):
         self.key.ks_pbs_device(ct.ct, ids, out, count, torch.cuda.current_stream().cuda_stream)
         ct.ct = out
 
+    def bootstrap_of_combination_assign(self, ct: Ciphertext, alpha: int, other: Ciphertext, beta: int,
+                                        acc: LookupTable) -> None:
+        """ct <- bootstrap(alpha*ct + beta*other) with ``acc``: the shift-and-add and the bootstrap
+        of engine/server_side/mod.rs:182-195. A device-resident batch goes through one call
+        (``camd_axpby_ks_pbs_batch_device``: the keyswitch forms the combination while it reads);
+        everything else takes the linear pass and then the bootstrap. Degree is not touched."""
+        deferred = self._queue is not None or getattr(self._tls, "gather", None) is not None
+        if deferred or isinstance(ct.ct, np.ndarray) or ct.ct.ndim != 2:
+            ct.ct = self._lin(ct.ct, alpha, other.ct, beta)
+            self.keyswitch_programmable_bootstrap_assign(ct, acc)
+            return
+        import torch
+
+        count = ct.ct.shape[0]
+        ids = self._device_ids.get((acc.lut_id, count))
+        if ids is None:
+            ids = torch.full((count,), acc.lut_id, dtype=torch.int32, device=ct.ct.device)
+            self._device_ids[(acc.lut_id, count)] = ids
+        out = torch.empty((count, ct.ct.shape[1]), dtype=ct.ct.dtype, device=ct.ct.device)
+        self.key.axpby_ks_pbs_device(ct.ct, alpha, other.ct, beta, 0, ids, out, torch.cuda.current_stream().cuda_stream)
+        ct.ct = out
+
     def keyswitch_bootstrap(self, ct: Ciphertext) -> Ciphertext:
         """server_key/mod.rs:172-175 -> engine/server_side/mod.rs:85-118 (default accumulator)."""
         return self.keyswitch_programmable_bootstrap(ct, self._default_acc)

@@ -464,11 +464,10 @@ class ShortintOps:
 
     def unchecked_functional_bivariate_pbs_assign(self, lhs, rhs, f: Callable[[int], int]) -> None:
         """engine/server_side/mod.rs:172-196: lhs*(deg_r+1) + rhs, then one bootstrap with f.
-        The shift and the add are one fused pass here."""
+        On a device-resident batch the shift and the add ride on the keyswitch's loads."""
         modulus = rhs.degree + 1
-        lhs.ct = self._lin(lhs.ct, modulus & 0xFF, rhs.ct, 1)
+        self.bootstrap_of_combination_assign(lhs, modulus & 0xFF, rhs, 1, self.generate_accumulator(f))
         lhs.degree = lhs.degree * (modulus & 0xFF) + rhs.degree
-        self._pbs(lhs, f)
 
     def _bivariate_smart_prepare(self, lhs, rhs) -> None:
         if not self.is_functional_bivariate_pbs_possible(lhs, rhs):

@@ -212,6 +212,27 @@ int camd_lwe_axpby_device(camd_context* ctx, uint32_t torus_bits, void* out, siz
                           size_t y_stride, uint64_t beta, uint64_t body_add, size_t words,
                           size_t count, void* stream);
 
+/* ---- a leveled operation and the bootstrap that follows it, as one call ----
+ * camd_ks_pbs_batch_device / camd_pbs_ks_batch_device on the rows alpha * x[c] + beta * y[c] with
+ * body_add added to the body, as camd_lwe_axpby_device would have written them (same argument
+ * meaning; the row length is that of the operation's input ciphertexts). The combination is not
+ * written to memory where the first kernel of the operation can form it while it reads its input:
+ * every keyswitch kernel (shortint order), and the bootstrap kernels of the block and generic
+ * families. For the wave family's bootstrap kernels (boolean order) the library writes it to
+ * scratch of the key first, inside the same call; results are the same either way. ct_out may
+ * alias x or y.
+ * Replaces, as one launch sequence, the shift-and-add followed by the bootstrap of a bivariate
+ * operation (concrete-shortint/src/engine/server_side/mod.rs:172-196) and a gate's linear
+ * combination followed by bootstrap_keyswitch (concrete-boolean/src/engine/mod.rs:364-405). */
+int camd_axpby_ks_pbs_batch_device(camd_server_key* key, const void* x, size_t x_stride,
+                                   uint64_t alpha, const void* y, size_t y_stride, uint64_t beta,
+                                   uint64_t body_add, const uint32_t* lut_ids, void* ct_out,
+                                   size_t count, void* stream);
+int camd_axpby_pbs_ks_batch_device(camd_server_key* key, const void* x, size_t x_stride,
+                                   uint64_t alpha, const void* y, size_t y_stride, uint64_t beta,
+                                   uint64_t body_add, const uint32_t* lut_ids, void* ct_out,
+                                   size_t count, void* stream);
+
 /* ---- measurement helpers ----
  * Average device time in milliseconds of the bootstrap kernel (and of the keyswitch kernel)
  * over the launches made since the last reset, taken with HIP events on the stream the

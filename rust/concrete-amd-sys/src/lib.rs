@@ -80,6 +80,8 @@ extern "C" {
     pub fn camd_pbs_batch_device(key: *mut CamdServerKey, ct_in: *const c_void, lut_ids: *const u32, ct_out: *mut c_void, count: usize, stream: *mut c_void) -> c_int;
     pub fn camd_ks_batch_device(key: *mut CamdServerKey, ct_in: *const c_void, ct_out: *mut c_void, count: usize, stream: *mut c_void) -> c_int;
     pub fn camd_lwe_axpby_device(ctx: *mut CamdContext, torus_bits: u32, out: *mut c_void, out_stride: usize, x: *const c_void, x_stride: usize, alpha: u64, y: *const c_void, y_stride: usize, beta: u64, body_add: u64, words: usize, count: usize, stream: *mut c_void) -> c_int;
+    pub fn camd_axpby_ks_pbs_batch_device(key: *mut CamdServerKey, x: *const c_void, x_stride: usize, alpha: u64, y: *const c_void, y_stride: usize, beta: u64, body_add: u64, lut_ids: *const u32, ct_out: *mut c_void, count: usize, stream: *mut c_void) -> c_int;
+    pub fn camd_axpby_pbs_ks_batch_device(key: *mut CamdServerKey, x: *const c_void, x_stride: usize, alpha: u64, y: *const c_void, y_stride: usize, beta: u64, body_add: u64, lut_ids: *const u32, ct_out: *mut c_void, count: usize, stream: *mut c_void) -> c_int;
     pub fn camd_timing_enable(key: *mut CamdServerKey, enable: c_int) -> c_int;
     pub fn camd_measure_fp64_fma_rate(ctx: *mut CamdContext, tflops: *mut f64) -> c_int;
     pub fn camd_timing_read(key: *mut CamdServerKey, pbs_ms_avg: *mut f64, pbs_launches: *mut u64, ks_ms_avg: *mut f64, ks_launches: *mut u64) -> c_int;
