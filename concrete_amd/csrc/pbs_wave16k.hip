@@ -330,6 +330,11 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   using G = Geo<LOGN>;
   constexpr int N = G::N, M = G::M, PTS = G::PTS, SUBS = G::SUBS, CPW = G::CPW;
   constexpr int R = 2;                    // k + 1
+  // Whether the barrier that frees the image after the last column's read replaces the one in front of
+  // the next CMUX's first image write. Measured: 2 to 3.5 % faster up to N = 8192; at N = 16384 the long
+  // stretch without a barrier lets the workgroups of an XCD drift apart on the key stream (1 to 4 % slower,
+  // unsteady).
+  constexpr bool FREE_EARLY = PTS <= 8;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
   double2* img = (double2*)(smem + T_LDS * sizeof(double2));
@@ -457,7 +462,9 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
 #pragma unroll
           for (int b = 0; b < CPW; b++) forward_step1<PTS>(z[b], load_step_factors<PTS>(a.tables, t));
           __builtin_amdgcn_sched_barrier(0);
-          __syncthreads();               // everyone is done with the image's previous content
+          // everyone is done with the image's previous content (with FREE_EARLY, the first transform of a
+          // CMUX has that from the barrier behind the last read of the inverse part)
+          if (!FREE_EARLY || r != 0 || l != L) __syncthreads();
 #pragma unroll
           for (int b = 0; b < CPW; b++)
 #pragma unroll
@@ -508,7 +515,8 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
         int t = t0;
         asm volatile("" : "+v"(t));
         const int lane = t & 63, wave = t >> 6;
-        __syncthreads();                 // everyone is done with the image's previous content
+        // No barrier ahead of the sub-transforms: the first column follows this wave's own forward
+        // sub-transforms, which touched its own rows only, and the second one the barrier below.
 #ifdef W16_DEBUG_KERNELS
         if (blockIdx.x == 0 && (int)i == dump_iteration && c == dump_column)
           for (int e = 0; e < SUBS; e++)
@@ -526,6 +534,11 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
         for (int b = 0; b < CPW; b++)
 #pragma unroll
           for (int k = 0; k < PTS; k++) z[b][k] = img[(b * PTS + k) * THREADS + t];
+        // The image is free for its next writer (the next column's sub-transforms, or the first forward
+        // transform of the next CMUX) as soon as everyone has read it: with the barrier here, where the
+        // waves still run together, a wave goes from its update straight into compute of its own while
+        // its neighbour on the SIMD waits for memory.
+        if (FREE_EARLY || c + 1 < R) __syncthreads();
 #pragma unroll
         for (int b = 0; b < CPW; b++) inverse_step2<PTS>(z[b], load_step_factors<PTS>(a.tables, t));
 #ifdef W16_DEBUG_KERNELS
@@ -549,8 +562,10 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
           }
         }
       }
-      __syncthreads();                   // the next gather reads what other threads just wrote
+      // No barrier here: the next gather reads row 0, whose update was complete before the barriers of
+      // the second column; row 1 is read after the barriers of row 0's transforms.
     }
+    __syncthreads();                     // the extraction reads what other threads just wrote
 
     // sample extraction of coefficient 0; the low dwords are zero
 #pragma unroll
