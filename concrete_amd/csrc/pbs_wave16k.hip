@@ -75,6 +75,14 @@ template <int LOGN>
 constexpr size_t slab_bytes() { return 2 * (size_t)Geo<LOGN>::N * sizeof(uint32_t); }   // accumulator of one ciphertext (k + 1 = 2 polynomials)
 template <int LOGN>
 constexpr size_t group_slab_bytes() { return Geo<LOGN>::CPW * slab_bytes<LOGN>(); }   // of a workgroup's ciphertexts
+// Two levels: what the lower level's digit leaves of a rotated difference IS the upper level's digit, 16
+// bits of it. A thread parks those of its points (two coefficients to a dword) behind the accumulators
+// while it forms the lower level's transform input and reads them back for the upper level's, instead
+// of gathering the difference again: 4 bytes per point and direction in place of 16 gathered.
+template <int LOGN>
+constexpr size_t parked_bytes() { return (size_t)Geo<LOGN>::ROWS * THREADS * sizeof(uint32_t); }
+template <int LOGN>
+constexpr size_t group_scratch_bytes() { return group_slab_bytes<LOGN>() + parked_bytes<LOGN>(); }
 
 // e^{i pi a/32}, a = 0..15: the per-register part of the twist
 __device__ __forceinline__ double2 twist16(int a) {
@@ -327,6 +335,7 @@ __device__ int dump_iteration = 0, dump_column = 0;
 template <typename T, int LOGN, int L, int BL>
 __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   static_assert(sizeof(T) == 8 && BL * L <= 33 && BL * L != 31 && BL * L != 32, "64-bit torus whose digits lie in the high dword");
+  static_assert(L != 2 || BL <= 15, "the parked upper digit has 16 bits");
   using G = Geo<LOGN>;
   constexpr int N = G::N, M = G::M, PTS = G::PTS, SUBS = G::SUBS, CPW = G::CPW;
   constexpr int R = 2;                    // k + 1
@@ -342,7 +351,9 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   __syncthreads();
 
   const int t0 = threadIdx.x;
-  uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * group_slab_bytes<LOGN>());   // [ciphertext][R][N] paired layout
+  uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * group_scratch_bytes<LOGN>());   // [ciphertext][R][N] paired layout
+  constexpr bool PARK = L == 2 && PTS % 4 == 0;
+  uint4* parked = (uint4*)((char*)acc + group_slab_bytes<LOGN>());   // [ciphertext][PTS / 4][thread]: this thread's points 4g .. 4g+3
   const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.fbsk, 0, (int)0x7FFFFFFF, 0x00020000);   // offsets are formed per iteration: the base moves with it
   const uint32_t n = a.n;
@@ -404,9 +415,24 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
           // this wave's rows of a key polynomial (the waves of different ciphertexts read the same rows)
           const uint32_t key_lane = (uint32_t)lane * 16u + (uint32_t)(CPW == 1 ? wave : wave % PTS) * (uint32_t)(SUBS * 8192);
           double2 z[CPW][PTS];
+          if (PARK && l == 1) {
+            // the upper level's digits were parked by this thread when it formed the lower level's
+#pragma unroll
+            for (int b = 0; b < CPW; b++)
+#pragma unroll
+              for (int g = 0; g < PTS / 4; g++) {
+                const uint4 w = parked[(b * (PTS / 4) + g) * THREADS + t];
+                const uint32_t pk[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int h = 0; h < 4; h++)
+                  z[b][4 * g + h] = make_double2((double)(int32_t)__builtin_amdgcn_sbfe((int32_t)pk[h], 0, 16),
+                                                 (double)((int32_t)pk[h] >> 16));
+              }
+          } else {
 #pragma unroll
           for (int b = 0; b < CPW; b++) {
           const uint32_t* p = acc + b * R * N + r * N;
+          uint32_t pk[PARK ? PTS : 1];
 #pragma unroll
           for (int q = 0; q < PTS; q++) {
             const uint32_t j0 = 512 * q + t;                                   // and j0 + M
@@ -445,11 +471,19 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             }
             if (l > 1) {
               const int width = l == L ? BL - SHORT : BL, scale = l == L ? SHORT : 0;
-              v0 = (int32_t)__builtin_amdgcn_sbfe(v0, 0, width) << scale;
-              v1 = (int32_t)__builtin_amdgcn_sbfe(v1, 0, width) << scale;
+              const int32_t d0 = (int32_t)__builtin_amdgcn_sbfe(v0, 0, width), d1 = (int32_t)__builtin_amdgcn_sbfe(v1, 0, width);
+              if constexpr (PARK)    // (v - d) >> BL lies in [-2^(BL-1), 2^(BL-1)]: 16 bits hold it for BL = 15
+                pk[q] = ((uint32_t)((v0 - d0) >> BL) & 0xFFFFu) | ((uint32_t)((v1 - d1) >> BL) << 16);
+              v0 = d0 << scale;
+              v1 = d1 << scale;
             }
             z[b][q] = make_double2((double)v0, (double)v1);
-            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four points' loads in flight at a time: registers are short
+            if ((q & 3) == 3) {
+              if constexpr (PARK)
+                parked[(b * (PTS / 4) + (q >> 2)) * THREADS + t] = make_uint4(pk[q - 3], pk[q - 2], pk[q - 1], pk[q]);
+              __builtin_amdgcn_sched_barrier(0);   // four points' loads in flight at a time: registers are short
+            }
+          }
           }
           }
 #ifdef W16_DEBUG_KERNELS
@@ -654,7 +688,8 @@ size_t wave16k_scratch_bytes(uint32_t N, unsigned* grid_out, size_t count, int c
   const size_t per_group = N >= 8192 ? 1 : 8192 / N;      // ciphertexts per workgroup (Geo::CPW)
   const unsigned grid = (unsigned)std::min<size_t>((count + per_group - 1) / per_group, (size_t)(cus > 0 ? cus : 1));
   if (grid_out) *grid_out = grid;
-  return (size_t)grid * per_group * 2 * N * sizeof(uint32_t);
+  const size_t rows = N >= 16384 ? 16 : 8;                  // image rows of a workgroup (Geo::ROWS)
+  return (size_t)grid * (per_group * 2 * N * sizeof(uint32_t) + rows * 512 * sizeof(uint32_t));   // Geo: group_scratch_bytes
 }
 
 void wave16k_fill_tables(uint32_t N, double2* t) {
