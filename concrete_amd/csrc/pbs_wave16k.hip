@@ -70,8 +70,6 @@ constexpr int T_TOTAL = T_V8 + THREADS;
 template <int LOGN>
 constexpr size_t image_bytes() { return (size_t)Geo<LOGN>::ROWS * THREADS * sizeof(double2); }   // 128 KB or 64 KB
 template <int LOGN>
-constexpr size_t lds_bytes() { return T_LDS * sizeof(double2) + image_bytes<LOGN>(); }
-template <int LOGN>
 constexpr size_t slab_bytes() { return 2 * (size_t)Geo<LOGN>::N * sizeof(uint32_t); }   // accumulator of one ciphertext (k + 1 = 2 polynomials)
 template <int LOGN>
 constexpr size_t group_slab_bytes() { return Geo<LOGN>::CPW * slab_bytes<LOGN>(); }   // of a workgroup's ciphertexts
@@ -83,6 +81,13 @@ template <int LOGN>
 constexpr size_t parked_bytes() { return (size_t)Geo<LOGN>::ROWS * THREADS * sizeof(uint32_t); }
 template <int LOGN>
 constexpr size_t group_scratch_bytes() { return group_slab_bytes<LOGN>() + parked_bytes<LOGN>(); }
+// ... in the LDS where the image leaves room for them (up to N = 8192), else in that global scratch
+template <int LOGN>
+constexpr bool parked_in_lds() { return T_LDS * sizeof(double2) + image_bytes<LOGN>() + parked_bytes<LOGN>() <= 160 * 1024; }
+template <int LOGN>
+constexpr size_t lds_bytes() {
+  return T_LDS * sizeof(double2) + image_bytes<LOGN>() + (parked_in_lds<LOGN>() ? parked_bytes<LOGN>() : 0);
+}
 
 // e^{i pi a/32}, a = 0..15: the per-register part of the twist
 __device__ __forceinline__ double2 twist16(int a) {
@@ -353,7 +358,9 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   const int t0 = threadIdx.x;
   uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * group_scratch_bytes<LOGN>());   // [ciphertext][R][N] paired layout
   constexpr bool PARK = L == 2 && PTS % 4 == 0;
-  uint4* parked = (uint4*)((char*)acc + group_slab_bytes<LOGN>());   // [ciphertext][PTS / 4][thread]: this thread's points 4g .. 4g+3
+  // [ciphertext][PTS / 4][thread]: this thread's points 4g .. 4g+3
+  uint4* parked = parked_in_lds<LOGN>() ? (uint4*)(smem + T_LDS * sizeof(double2) + image_bytes<LOGN>())
+                                        : (uint4*)((char*)acc + group_slab_bytes<LOGN>());
   const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.fbsk, 0, (int)0x7FFFFFFF, 0x00020000);   // offsets are formed per iteration: the base moves with it
   const uint32_t n = a.n;
