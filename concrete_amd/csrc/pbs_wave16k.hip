@@ -79,8 +79,14 @@ constexpr size_t group_slab_bytes() { return Geo<LOGN>::CPW * slab_bytes<LOGN>()
 // of gathering the difference again: 4 bytes per point and direction in place of 16 gathered.
 template <int LOGN>
 constexpr size_t parked_bytes() { return (size_t)Geo<LOGN>::ROWS * THREADS * sizeof(uint32_t); }
-template <int LOGN>
-constexpr size_t group_scratch_bytes() { return group_slab_bytes<LOGN>() + parked_bytes<LOGN>(); }
+// Distance between the accumulators of consecutive workgroups. A power of two makes the 32 slabs of an XCD
+// fall on the same sets of its L2; one page more costs nothing and measured 3 to 4 % faster at
+// N = 16384 and N = 4096 (no difference at 8192 and 2048; any pad from 4 to 40 KB did the same). The
+// three-level instance is the exception (138 ms per 512 unpadded against 145 to 157 padded) and keeps
+// the power of two. The scratch is sized for the padded stride in either case.
+constexpr size_t SLAB_PAD = 4096;
+template <int LOGN, int L>
+constexpr size_t group_stride_bytes() { return group_slab_bytes<LOGN>() + (L == 3 ? 0 : SLAB_PAD); }
 // ... in the LDS where the image leaves room for them (up to N = 8192), else in that global scratch
 template <int LOGN>
 constexpr bool parked_in_lds() { return T_LDS * sizeof(double2) + image_bytes<LOGN>() + parked_bytes<LOGN>() <= 160 * 1024; }
@@ -356,11 +362,12 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   __syncthreads();
 
   const int t0 = threadIdx.x;
-  uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * group_scratch_bytes<LOGN>());   // [ciphertext][R][N] paired layout
+  uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * group_stride_bytes<LOGN, L>());   // [ciphertext][R][N] paired layout
   constexpr bool PARK = L == 2 && PTS % 4 == 0;
   // [ciphertext][PTS / 4][thread]: this thread's points 4g .. 4g+3
   uint4* parked = parked_in_lds<LOGN>() ? (uint4*)(smem + T_LDS * sizeof(double2) + image_bytes<LOGN>())
-                                        : (uint4*)((char*)acc + group_slab_bytes<LOGN>());
+                                        : (uint4*)((char*)a.scratch + (size_t)gridDim.x * group_stride_bytes<LOGN, L>() +
+                                                   (size_t)blockIdx.x * parked_bytes<LOGN>());   // behind all accumulators
   const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.fbsk, 0, (int)0x7FFFFFFF, 0x00020000);   // offsets are formed per iteration: the base moves with it
   const uint32_t n = a.n;
@@ -696,7 +703,8 @@ size_t wave16k_scratch_bytes(uint32_t N, unsigned* grid_out, size_t count, int c
   const unsigned grid = (unsigned)std::min<size_t>((count + per_group - 1) / per_group, (size_t)(cus > 0 ? cus : 1));
   if (grid_out) *grid_out = grid;
   const size_t rows = N >= 16384 ? 16 : 8;                  // image rows of a workgroup (Geo::ROWS)
-  return (size_t)grid * (per_group * 2 * N * sizeof(uint32_t) + rows * 512 * sizeof(uint32_t));   // Geo: group_scratch_bytes
+  // per workgroup: accumulators at the padded stride (w16::group_stride_bytes), then the parked digits of all
+  return (size_t)grid * (per_group * 2 * N * sizeof(uint32_t) + w16::SLAB_PAD + rows * 512 * sizeof(uint32_t));
 }
 
 void wave16k_fill_tables(uint32_t N, double2* t) {
