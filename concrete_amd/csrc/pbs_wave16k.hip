@@ -90,9 +90,15 @@ constexpr size_t group_stride_bytes() { return group_slab_bytes<LOGN>() + (L == 
 // ... in the LDS where the image leaves room for them (up to N = 8192), else in that global scratch
 template <int LOGN>
 constexpr bool parked_in_lds() { return T_LDS * sizeof(double2) + image_bytes<LOGN>() + parked_bytes<LOGN>() <= 160 * 1024; }
+// N = 16384: the LDS that image and tables leave (13 KB) takes the digits of the first four points of
+// every thread (8 KB); the other twelve go to the global scratch (2 % faster than all sixteen there)
+template <int LOGN>
+constexpr int parked_lds_groups() {
+  return parked_in_lds<LOGN>() ? 0 : (int)((160 * 1024 - T_LDS * sizeof(double2) - image_bytes<LOGN>()) / (THREADS * sizeof(uint4)));
+}
 template <int LOGN>
 constexpr size_t lds_bytes() {
-  return T_LDS * sizeof(double2) + image_bytes<LOGN>() + (parked_in_lds<LOGN>() ? parked_bytes<LOGN>() : 0);
+  return T_LDS * sizeof(double2) + image_bytes<LOGN>() + (parked_in_lds<LOGN>() ? parked_bytes<LOGN>() : parked_lds_groups<LOGN>() * THREADS * sizeof(uint4));
 }
 
 // e^{i pi a/32}, a = 0..15: the per-register part of the twist
@@ -435,7 +441,9 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             for (int b = 0; b < CPW; b++)
 #pragma unroll
               for (int g = 0; g < PTS / 4; g++) {
-                const uint4 w = parked[(b * (PTS / 4) + g) * THREADS + t];
+                const uint4 w = (g < parked_lds_groups<LOGN>())
+                                    ? ((const uint4*)(smem + T_LDS * sizeof(double2) + image_bytes<LOGN>()))[g * THREADS + t]
+                                    : parked[(b * (PTS / 4) + g) * THREADS + t];
                 const uint32_t pk[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                 for (int h = 0; h < 4; h++)
@@ -494,7 +502,10 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             z[b][q] = make_double2((double)v0, (double)v1);
             if ((q & 3) == 3) {
               if constexpr (PARK)
-                parked[(b * (PTS / 4) + (q >> 2)) * THREADS + t] = make_uint4(pk[q - 3], pk[q - 2], pk[q - 1], pk[q]);
+                if ((q >> 2) < parked_lds_groups<LOGN>())
+                  ((uint4*)(smem + T_LDS * sizeof(double2) + image_bytes<LOGN>()))[(q >> 2) * THREADS + t] = make_uint4(pk[q - 3], pk[q - 2], pk[q - 1], pk[q]);
+                else
+                  parked[(b * (PTS / 4) + (q >> 2)) * THREADS + t] = make_uint4(pk[q - 3], pk[q - 2], pk[q - 1], pk[q]);
               __builtin_amdgcn_sched_barrier(0);   // four points' loads in flight at a time: registers are short
             }
           }
