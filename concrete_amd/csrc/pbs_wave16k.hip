@@ -356,11 +356,10 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   using G = Geo<LOGN>;
   constexpr int N = G::N, M = G::M, PTS = G::PTS, SUBS = G::SUBS, CPW = G::CPW;
   constexpr int R = 2;                    // k + 1
-  // Whether the barrier that frees the image after the last column's read replaces the one in front of
-  // the next CMUX's first image write. Measured: 2 to 3.5 % faster up to N = 8192; at N = 16384 the long
-  // stretch without a barrier lets the workgroups of an XCD drift apart on the key stream (1 to 4 % slower,
-  // unsteady).
-  constexpr bool FREE_EARLY = PTS <= 8;
+  // The barrier that frees the image after the last column's read replaces the one in front of the next
+  // CMUX's first image write (1 to 3.5 % faster at every size once the slabs were padded and the upper
+  // digits parked; before that the N = 16384 instances lost 1 % to it).
+  constexpr bool FREE_EARLY = true;
   extern __shared__ __align__(16) char smem[];
   double2* tab = (double2*)smem;
   double2* img = (double2*)(smem + T_LDS * sizeof(double2));
