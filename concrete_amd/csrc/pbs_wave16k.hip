@@ -88,17 +88,24 @@ constexpr size_t SLAB_PAD = 4096;
 template <int LOGN, int L>
 constexpr size_t group_stride_bytes() { return group_slab_bytes<LOGN>() + (L == 3 ? 0 : SLAB_PAD); }
 // ... in the LDS where the image leaves room for them (up to N = 8192), else in that global scratch
+// Up to N = 8192 the LDS holds TWO images, used in turn: a transform's image is then written while the
+// previous one's rows are still being read, and the barrier in front of every image write (the one
+// that stands behind a phase of memory waits) is not needed; one barrier per image remains.
 template <int LOGN>
-constexpr bool parked_in_lds() { return T_LDS * sizeof(double2) + image_bytes<LOGN>() + parked_bytes<LOGN>() <= 160 * 1024; }
+constexpr int images() { return T_LDS * sizeof(double2) + 2 * image_bytes<LOGN>() <= 160 * 1024 ? 2 : 1; }
+template <int LOGN>
+constexpr size_t images_bytes() { return images<LOGN>() * image_bytes<LOGN>(); }
+template <int LOGN>
+constexpr bool parked_in_lds() { return T_LDS * sizeof(double2) + images_bytes<LOGN>() + parked_bytes<LOGN>() <= 160 * 1024; }
 // N = 16384: the LDS that image and tables leave (13 KB) takes the digits of the first four points of
 // every thread (8 KB); the other twelve go to the global scratch (2 % faster than all sixteen there)
 template <int LOGN>
 constexpr int parked_lds_groups() {
-  return parked_in_lds<LOGN>() ? 0 : (int)((160 * 1024 - T_LDS * sizeof(double2) - image_bytes<LOGN>()) / (THREADS * sizeof(uint4)));
+  return parked_in_lds<LOGN>() ? 0 : (int)((160 * 1024 - T_LDS * sizeof(double2) - images_bytes<LOGN>()) / (THREADS * sizeof(uint4)));
 }
 template <int LOGN>
 constexpr size_t lds_bytes() {
-  return T_LDS * sizeof(double2) + image_bytes<LOGN>() + (parked_in_lds<LOGN>() ? parked_bytes<LOGN>() : parked_lds_groups<LOGN>() * THREADS * sizeof(uint4));
+  return T_LDS * sizeof(double2) + images_bytes<LOGN>() + (parked_in_lds<LOGN>() ? parked_bytes<LOGN>() : parked_lds_groups<LOGN>() * THREADS * sizeof(uint4));
 }
 
 // e^{i pi a/32}, a = 0..15: the per-register part of the twist
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
   uint32_t* acc = (uint32_t*)((char*)a.scratch + (size_t)blockIdx.x * group_stride_bytes<LOGN, L>());   // [ciphertext][R][N] paired layout
   constexpr bool PARK = L == 2 && PTS % 4 == 0;
   // [ciphertext][PTS / 4][thread]: this thread's points 4g .. 4g+3
-  uint4* parked = parked_in_lds<LOGN>() ? (uint4*)(smem + T_LDS * sizeof(double2) + image_bytes<LOGN>())
+  uint4* parked = parked_in_lds<LOGN>() ? (uint4*)(smem + T_LDS * sizeof(double2) + images_bytes<LOGN>())
                                         : (uint4*)((char*)a.scratch + (size_t)gridDim.x * group_stride_bytes<LOGN, L>() +
                                                    (size_t)blockIdx.x * parked_bytes<LOGN>());   // behind all accumulators
   const __amdgpu_buffer_rsrc_t key_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -440,8 +447,8 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             for (int b = 0; b < CPW; b++)
 #pragma unroll
               for (int g = 0; g < PTS / 4; g++) {
-                const uint4 w = (g < parked_lds_groups<LOGN>())
-                                    ? ((const uint4*)(smem + T_LDS * sizeof(double2) + image_bytes<LOGN>()))[g * THREADS + t]
+                const uint4 w = (b * (PTS / 4) + g < parked_lds_groups<LOGN>())
+                                    ? ((const uint4*)(smem + T_LDS * sizeof(double2) + images_bytes<LOGN>()))[(b * (PTS / 4) + g) * THREADS + t]
                                     : parked[(b * (PTS / 4) + g) * THREADS + t];
                 const uint32_t pk[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -501,8 +508,8 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             z[b][q] = make_double2((double)v0, (double)v1);
             if ((q & 3) == 3) {
               if constexpr (PARK)
-                if ((q >> 2) < parked_lds_groups<LOGN>())
-                  ((uint4*)(smem + T_LDS * sizeof(double2) + image_bytes<LOGN>()))[(q >> 2) * THREADS + t] = make_uint4(pk[q - 3], pk[q - 2], pk[q - 1], pk[q]);
+                if (b * (PTS / 4) + (q >> 2) < parked_lds_groups<LOGN>())
+                  ((uint4*)(smem + T_LDS * sizeof(double2) + images_bytes<LOGN>()))[(b * (PTS / 4) + (q >> 2)) * THREADS + t] = make_uint4(pk[q - 3], pk[q - 2], pk[q - 1], pk[q]);
                 else
                   parked[(b * (PTS / 4) + (q >> 2)) * THREADS + t] = make_uint4(pk[q - 3], pk[q - 2], pk[q - 1], pk[q]);
               __builtin_amdgcn_sched_barrier(0);   // four points' loads in flight at a time: registers are short
@@ -522,11 +529,14 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
           __builtin_amdgcn_sched_barrier(0);
           // everyone is done with the image's previous content (with FREE_EARLY, the first transform of a
           // CMUX has that from the barrier behind the last read of the inverse part)
-          if (!FREE_EARLY || r != 0 || l != L) __syncthreads();
+          // (with two images the previous content is two barriers old: nothing to wait for)
+          constexpr bool TWO = images<LOGN>() == 2;
+          double2* const im = img + (TWO ? ((r * L + (L - l)) & 1) * (G::ROWS * THREADS) : 0);
+          if (!TWO && (!FREE_EARLY || r != 0 || l != L)) __syncthreads();
 #pragma unroll
           for (int b = 0; b < CPW; b++)
 #pragma unroll
-            for (int k = 0; k < PTS; k++) img[(b * PTS + k) * THREADS + t] = z[b][k];
+            for (int k = 0; k < PTS; k++) im[(b * PTS + k) * THREADS + t] = z[b][k];
           __syncthreads();
           // the two sub-transforms of this wave, one after the other, each followed by its products
           const uint32_t key_base = (uint32_t)(((size_t)i * L + (l - 1)) * R + r) * (uint32_t)(R * M * sizeof(double2));
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
           for (int e = 0; e < SUBS; e++) {
             double2 x[8];
 #pragma unroll
-            for (int g = 0; g < 8; g++) x[g] = img[(SUBS * wave + e) * THREADS + 64 * g + lane];
+            for (int g = 0; g < 8; g++) x[g] = im[(SUBS * wave + e) * THREADS + 64 * g + lane];
             fft512_plain_forward_head(x, lane, tab);
             __builtin_amdgcn_sched_barrier(0);
             // the key values of the first column are requested in front of the last exchange and pass, those of the second
@@ -555,7 +565,7 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
             request(0);
             if constexpr (PTS <= 8) request(1);     // (the smaller sizes have the registers for both)
             __builtin_amdgcn_sched_barrier(0);
-            fft512_plain_forward_tail(x, lane, tab, img + (SUBS * wave + e) * THREADS);
+            fft512_plain_forward_tail(x, lane, tab, im + (SUBS * wave + e) * THREADS);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PTS > 8) request(1);
 #pragma unroll
@@ -573,6 +583,8 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
         int t = t0;
         asm volatile("" : "+v"(t));
         const int lane = t & 63, wave = t >> 6;
+        constexpr bool TWO = images<LOGN>() == 2;
+        double2* const im = img + (TWO ? (c & 1) * (G::ROWS * THREADS) : 0);   // (the forward part took an even number of images)
         // No barrier ahead of the sub-transforms: the first column follows this wave's own forward
         // sub-transforms, which touched its own rows only, and the second one the barrier below.
 #ifdef W16_DEBUG_KERNELS
@@ -582,21 +594,21 @@ __global__ __launch_bounds__(THREADS, 2) void pbs_kernel(PbsLaunch<T> a) {
 #endif
 #pragma unroll
         for (int e = 0; e < SUBS; e++) {
-          fft512_plain_inverse(S[c][e], lane, tab, img + (SUBS * wave + e) * THREADS);
+          fft512_plain_inverse(S[c][e], lane, tab, im + (SUBS * wave + e) * THREADS);
 #pragma unroll
-          for (int g = 0; g < 8; g++) img[(SUBS * wave + e) * THREADS + 64 * g + lane] = S[c][e][g];
+          for (int g = 0; g < 8; g++) im[(SUBS * wave + e) * THREADS + 64 * g + lane] = S[c][e][g];
         }
         __syncthreads();
         double2 z[CPW][PTS];
 #pragma unroll
         for (int b = 0; b < CPW; b++)
 #pragma unroll
-          for (int k = 0; k < PTS; k++) z[b][k] = img[(b * PTS + k) * THREADS + t];
+          for (int k = 0; k < PTS; k++) z[b][k] = im[(b * PTS + k) * THREADS + t];
         // The image is free for its next writer (the next column's sub-transforms, or the first forward
         // transform of the next CMUX) as soon as everyone has read it: with the barrier here, where the
         // waves still run together, a wave goes from its update straight into compute of its own while
         // its neighbour on the SIMD waits for memory.
-        if (FREE_EARLY || c + 1 < R) __syncthreads();
+        if (!TWO && (FREE_EARLY || c + 1 < R)) __syncthreads();
 #pragma unroll
         for (int b = 0; b < CPW; b++) inverse_step2<PTS>(z[b], load_step_factors<PTS>(a.tables, t));
 #ifdef W16_DEBUG_KERNELS
