@@ -295,14 +295,17 @@ __global__ __launch_bounds__(256) void bsk_fourier_kernel(const T* __restrict__ 
   for (int g = 0; g < 4; g++) dst[g * 64 + lane] = x[0][g];
 }
 
+// One step of the balanced decomposition, the digits of decomp_next() for every state below
+// 2^(32 - BL): with res the low BL bits, the carry is 1 for res > B/2 and, at res == B/2, the top bit of
+// the next digit's field. That is the carry out of bit BL - 1 of res + (B/2 - 1) + that bit, so the next
+// state is one add and one shift away and the digit is what is left of the state (four instructions
+// for seven).
 template <int BL>
 __device__ __forceinline__ int32_t next_digit(uint32_t& state) {
-  const uint32_t res = state & ((1u << BL) - 1u);
-  state >>= BL;
-  uint32_t carry = ((res - 1u) | state) & res;
-  carry >>= (BL - 1);
-  state += carry;
-  return (int32_t)(res - (carry << BL));
+  const uint32_t next = (state + ((1u << (BL - 1)) - 1u) + __builtin_amdgcn_ubfe(state, 2 * BL - 1, 1)) >> BL;
+  const int32_t digit = (int32_t)(state - (next << BL));
+  state = next;
+  return digit;
 }
 
 // STREAM: no key slab is parked; the key values of a CMUX come from the L2 inside its

@@ -81,6 +81,10 @@ __device__ __forceinline__ uint32_t digit_state32(T x) {
     // mask would drop anyway
     constexpr int S = NON_REP - 32;
     return ((hi + (1u << (S - 1))) >> S) & ((1u << (BL * L)) - 1u);
+  } else if constexpr (BITS == 32) {
+    // ((x >> (NON_REP - 1)) + 1) >> 1, masked to BL L bits: the same bits as one add and one shift
+    // (a carry out of bit 31 is the masked-off bit)
+    return ((uint32_t)x + (1u << (NON_REP - 1))) >> NON_REP;
   } else {
     return (uint32_t)decomp_init_state<T>(x, BL, L);
   }
@@ -93,7 +97,13 @@ __device__ __forceinline__ int32_t digit_next32(uint32_t& state) {
     const uint32_t res = state;
     return (int32_t)res - ((res > (1u << (BL - 1))) ? (1 << BL) : 0);
   } else {
-    return (int32_t)decomp_next<uint32_t>(state, BL);
+    // decomp_next() in four instructions, for states below 2^(32 - BL): the carry (res > B/2, or
+    // res == B/2 and the top bit of the next digit's field set) is the carry out of bit BL - 1 of
+    // res + (B/2 - 1) + that bit
+    const uint32_t next = (state + ((1u << (BL - 1)) - 1u) + __builtin_amdgcn_ubfe(state, 2 * BL - 1, 1)) >> BL;
+    const int32_t digit = (int32_t)(state - (next << BL));
+    state = next;
+    return digit;
   }
 }
 
