@@ -365,3 +365,27 @@ def test_headers_are_plain_c_and_the_c_driver_links():
                         os.path.join(inc, h)], check=True, capture_output=True)
     subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "c"), "-s"], check=True, capture_output=True)
     assert os.path.exists(os.path.join(ROOT, "tests", "c", "abi_driver"))
+
+
+def test_closed_form_of_the_balanced_digit_step():
+    """The multi-level wave kernels take a digit as state - (next << BL) with
+    next = (state + B/2 - 1 + bit(2 BL - 1 of state)) >> BL (csrc/wave_common.hpp: digit_next32,
+    csrc/pbs_wave512.hip: next_digit). That must be the decomposer's recurrence
+    (res = state & (B-1); state >>= BL; carry = ((res-1) | state) & res) >> (BL-1); ...), for every
+    state the kernels can hold: exhaustively up to 22 bits, sampled above."""
+    rng = np.random.RandomState(7)
+
+    def recurrence(s, bl):
+        res, st = s & ((1 << bl) - 1), s >> bl
+        carry = ((((res - 1) & 0xFFFFFFFF) | st) & res) >> (bl - 1)
+        return res - (carry << bl), (st + carry) & 0xFFFFFFFF
+
+    def closed(s, bl):
+        nxt = ((s + (1 << (bl - 1)) - 1 + ((s >> (2 * bl - 1)) & 1)) & 0xFFFFFFFF) >> bl
+        d = (s - (nxt << bl)) & 0xFFFFFFFF
+        return d - (1 << 32) if d >= 1 << 31 else d, nxt
+
+    for bl in (2, 3, 7, 8, 11, 15):
+        states = list(range(1 << min(2 * bl + 2, 18))) + [int(x) for x in rng.randint(0, 1 << (32 - bl), size=20000)]
+        for s in states:
+            assert recurrence(s, bl) == closed(s, bl), (bl, s)
